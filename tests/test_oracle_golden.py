@@ -1,0 +1,115 @@
+"""Pin the CPU oracle to the reference: it must reproduce, bit for bit, the vectors that
+oracle/gen_golden.py obtained by running the reference itself.
+
+Bit-exactness holds on the NumPy build the fixtures were made with (2.2.x on x86-64);
+the published known answers of the reference's own tests are checked at their stated
+tolerances regardless.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, same_bits
+from oracle import vfo_numpy as orc
+
+
+def test_constants_match_reference_kat():
+    g = load_golden("g3_index_kat.npz")
+    # reference test_core.py:38-44
+    assert np.allclose(g["constants"], [8.97866275, 2.799249247e10, 6371.0, 299_792.458], rtol=1e-8)
+    assert same_bits(g["constants"], [orc.PLASMA_CONST, orc.GYRO_CONST, orc.EARTH_RADIUS_KM,
+                                      orc.LIGHT_SPEED_KM_S])
+
+
+def test_stretch_multiplier():
+    g = load_golden("g3_index_kat.npz")
+    m = orc.stretch_multiplier(10)
+    assert same_bits(m, g["grid10"])
+    assert m[0] == 0.0 and m[-1] == 1.0 and np.all(np.diff(m) > 0)   # reference test_core.py:171-188
+
+
+def test_index_known_answers():
+    g = load_golden("g3_index_kat.npz")
+    mu, mup = orc.phase_group_index(g["X"], g["Y"], g["psi"], "O")
+    # published numbers, reference test_core.py:143-152
+    np.testing.assert_allclose(mu, g["mu_published"], rtol=1e-5)
+    np.testing.assert_allclose(mup, g["mup_published"], rtol=1e-5)
+    assert same_bits(mu, g["mu_O"]) and same_bits(mup, g["mup_O"])
+    with np.errstate(all="ignore"):
+        mu, mup = orc.phase_group_index(g["X"], g["Y"], g["psi"], "X")
+    assert same_bits(mu, g["mu_X"]) and same_bits(mup, g["mup_X"])
+    with np.errstate(all="ignore"):
+        mu, mup = orc.phase_group_index(g["unmag_X"], np.zeros(3), g["psi"], "O")
+    assert same_bits(mu, g["unmag_mu"]) and same_bits(mup, g["unmag_mup"])
+    vh = orc.group_path(np.array([[0.5, 0.6]]), np.array([[0.1, 0.2]]), np.array([[45.0, 45.0]]),
+                        np.array([[1.0, 1.0]]), 100.0, "O")
+    assert same_bits(vh, g["find_vh_small"])
+
+
+def test_index_rejects_bad_mode():
+    with pytest.raises(ValueError, match="Mode must be O or X"):
+        orc.phase_group_index(np.array([0.5]), np.array([0.1]), np.array([45.0]), "Z")
+
+
+def test_basic_operator_g1():
+    g = load_golden("g1_basic.npz")
+    for mode in "OX":
+        vh = orc.virtual_heights(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], mode, int(g["n_points"]))
+        assert same_bits(vh, g[f"vh_{mode}"])
+    # reference test_core.py:233-236
+    assert np.isnan(g["vh_O"][-1]) and np.all(np.isfinite(g["vh_O"][:-1]))
+
+
+def test_edp_known_answer_g2():
+    g = load_golden("g2_edp_kat.npz")
+    vh = orc.virtual_heights(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"])
+    assert same_bits(vh, g["vh_O"])
+    # the reference's published answer went through PyIRI's EDP, printed to 9 digits
+    np.testing.assert_allclose(vh, g["vh_published"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["Day", "Night"])
+@pytest.mark.parametrize("mode", ["O", "X"])
+@pytest.mark.parametrize("n_points", [200, 2000, 20000])
+def test_day_night_g4(which, mode, n_points):
+    g = load_golden("g4_day_night.npz")
+    vh = orc.virtual_heights(g["freq"], g[f"{which}_den"], g[f"{which}_bmag"], g[f"{which}_bpsi"],
+                             g[f"{which}_alt"], mode, n_points)
+    assert same_bits(vh, g[f"{which}_{mode}_{n_points}_vh"])
+
+
+def test_chapman_batch_g5():
+    g = load_golden("g5_chapman64.npz")
+    for mode, n in (("O", 200), ("X", 2000)):
+        sel = slice(0, 64) if n == 200 else slice(0, 12)      # keep the CPU suite short
+        vh = orc.virtual_heights_batch(g["freq"], g["den"][sel], g["bmag"][sel], g["bpsi"][sel],
+                                       g["alt"], mode, n)
+        assert same_bits(vh, g[f"{mode}_{n}_vh"][sel])
+
+
+def test_stage_captures_g6():
+    g = load_golden("g4_day_night.npz")
+    s = load_golden("g6_stages.npz")
+    for mode in "OX":
+        cap = orc.stage_capture(s["freq"], g["Day_den"], g["Day_bmag"], g["Day_bpsi"], g["Day_alt"], mode, 50)
+        for key in ("den", "bmag", "bpsi", "dist", "alt", "crit_height", "X", "Y", "mu", "mup", "vh"):
+            assert same_bits(cap[key], s[f"{mode}_{key}"]), (mode, key)
+
+
+def test_edge_cases_g7():
+    g = load_golden("g7_edges.npz")
+    names = sorted({k[: -len("_n_points")] for k in g if k.endswith("_n_points")})
+    assert len(names) >= 8
+    for name in names:
+        for mode in "OX":
+            vh = orc.virtual_heights(g[f"{name}_freq"], g[f"{name}_den"], g[f"{name}_bmag"],
+                                     g[f"{name}_bpsi"], g[f"{name}_alt"], mode, int(g[f"{name}_n_points"]))
+            assert same_bits(vh, g[f"{name}_vh_{mode}"]), (name, mode)
+
+
+def test_error_behaviour():
+    g = load_golden("g1_basic.npz")
+    with pytest.raises(ValueError, match="mode must be 'O' or 'X'"):       # reference library.py:395-396
+        orc.virtual_heights(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "Z", 10)
+    with pytest.raises(ValueError, match="Density must be non-negative"):  # reference library.py:93-94
+        orc.ratio_X(np.array([-1.0]), np.array([1e6]))
