@@ -1,0 +1,131 @@
+/*
+ * prhf.h - C ABI of libprhf.so, the MI355X (gfx950) vertical-ionogram forward operator.
+ *
+ * Drop-in boundary.  The reference has no FFI layer: its boundary is the Python function
+ *     PyRayHF.library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200)
+ * (reference PyRayHF/library.py:459-509).  The entry points below are what a ctypes binding
+ * for that function calls; pyrayhf_amd/library.py is that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all arrays are float64, C-contiguous rows;
+ *   - every function returns 0 (PRHF_OK) or a negative PRHF_E* code; prhf_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - the library borrows caller buffers for the duration of a call (or, with
+ *     PRHF_FLAG_ASYNC, until the next prhf_sync on that context) and owns nothing but its
+ *     context (stream, scratch, events);
+ *   - a context is bound to one device and is not thread-safe; different contexts are
+ *     independent and may be used from different threads.
+ *
+ * Units are the reference's (library.py:465-474): freq MHz, den m^-3, bmag Tesla,
+ * bpsi degrees, alt km; the result is virtual height in km, NaN where the sounder
+ * frequency is not reflected below the density peak.
+ */
+#ifndef PRHF_H
+#define PRHF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRHF_ABI_VERSION 1
+
+/* return codes */
+#define PRHF_OK        0
+#define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination */
+#define PRHF_ENEGDEN  -2   /* a density below the peak is negative (reference library.py:93-94 raises ValueError) */
+#define PRHF_EPEAK0   -3   /* density peak at index 0: empty bottomside (the reference raises IndexError) */
+#define PRHF_EHIP     -4   /* HIP runtime failure; message carries hipGetErrorString */
+#define PRHF_ENOMEM   -5   /* scratch allocation failed */
+
+/* wave modes: reference 'O' and 'X' (library.py:391-396, :221-226) */
+#define PRHF_MODE_O 0
+#define PRHF_MODE_X 1
+
+/* flags of prhf_vfo_batch_f64 / prhf_vfo_worklist_f64 */
+#define PRHF_FLAG_DEVICE_PTRS 0x1u  /* every array pointer (inputs, multiplier, output) is device memory */
+#define PRHF_FLAG_ASYNC       0x2u  /* device pointers only: enqueue and return; data errors surface at prhf_sync */
+
+/* arithmetic tiers, prhf_ctx_set_math (see DESIGN.md "Arithmetic tiers") */
+#define PRHF_MATH_FAITHFUL 0  /* reference operation order, IEEE divide/sqrt, no contraction */
+#define PRHF_MATH_FAST     1  /* shared reciprocals / rsqrt, contracted; X-mode error <= 1e-9 relative */
+
+typedef struct prhf_ctx prhf_ctx;
+
+/* One homogeneous slice of a mixed launch (BASELINE config 5): profiles [prof_begin, prof_end)
+ * are evaluated with one mode and one grid size.  mult_offset indexes the concatenated
+ * multiplier array; the slice's output rows start at vh_out + out_offset (row-major
+ * (prof_end - prof_begin, n_freq)). */
+typedef struct prhf_segment {
+    int64_t prof_begin;
+    int64_t prof_end;
+    int32_t mode;
+    int32_t n_points;
+    int64_t mult_offset;
+    int64_t out_offset;
+} prhf_segment;
+
+int prhf_abi_version(void);
+const char* prhf_last_error(void);
+int prhf_device_count(int* n);
+
+int prhf_ctx_create(int device, prhf_ctx** out);
+int prhf_ctx_destroy(prhf_ctx* ctx);
+
+/* Borrow a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own.
+ * Pass NULL to return to the context's stream. */
+int prhf_ctx_set_stream(prhf_ctx* ctx, void* hip_stream);
+
+/* Select the arithmetic tier (PRHF_MATH_*), default PRHF_MATH_FAITHFUL. */
+int prhf_ctx_set_math(prhf_ctx* ctx, int level);
+
+/*
+ * Virtual heights of n_prof profiles x n_freq sounder frequencies.
+ *
+ * Replaces: vertical_forward_operator (reference library.py:459-509) and everything below it
+ * (regrid_to_nonuniform_grid :324-438, find_X :120-137, find_Y :140-158, find_mu_mup :161-256,
+ * find_vh :259-293), evaluated once per profile row; semantics are a loop of single-profile
+ * reference calls.
+ *
+ *   freq_mhz    (n_freq)                       sounder frequencies, MHz
+ *   den,bmag,bpsi  n_prof rows of n_alt values, row p at ptr + p*prof_stride_elems
+ *   alt         (n_alt) shared by all profiles when alt_stride_elems == 0, else row p at
+ *               alt + p*alt_stride_elems; ascending
+ *   multiplier  (n_points) stretched unit grid, smooth_nonuniform_grid(0,1,n_points,10.)
+ *               (library.py:296-321, :361-364) computed by the host in float64
+ *   vh_out      (n_prof, n_freq) row-major
+ */
+int prhf_vfo_batch_f64(prhf_ctx* ctx,
+                       const double* freq_mhz, int64_t n_freq,
+                       const double* den, const double* bmag, const double* bpsi,
+                       const double* alt,
+                       int64_t n_prof, int64_t n_alt,
+                       int64_t prof_stride_elems, int64_t alt_stride_elems,
+                       const double* multiplier, int32_t n_points, int32_t mode,
+                       double* vh_out, uint32_t flags);
+
+/* Mixed O/X and mixed n_points in one launch.  multiplier is the concatenation of the
+ * segments' grids; segs is host memory in every flag combination. */
+int prhf_vfo_worklist_f64(prhf_ctx* ctx,
+                          const double* freq_mhz, int64_t n_freq,
+                          const double* den, const double* bmag, const double* bpsi,
+                          const double* alt,
+                          int64_t n_prof, int64_t n_alt,
+                          int64_t prof_stride_elems, int64_t alt_stride_elems,
+                          const double* multiplier, int64_t multiplier_len,
+                          const prhf_segment* segs, int32_t n_segs,
+                          double* vh_out, uint32_t flags);
+
+/* Wait for everything enqueued on the context; returns PRHF_ENEGDEN / PRHF_EPEAK0 if a
+ * kernel flagged bad input since the last sync. */
+int prhf_sync(prhf_ctx* ctx);
+
+/* Device time of the most recent launch (all kernels of that call), from HIP events on the
+ * context's stream.  Synchronises on the stop event. */
+int prhf_last_kernel_ms(prhf_ctx* ctx, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRHF_H */

@@ -1,0 +1,189 @@
+"""ctypes binding of libprhf.so (C ABI: include/prhf.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``make -C pyrayhf_amd/csrc`` and is the only compute path: if it is missing, or no GPU is
+visible, the operator raises - there is no CPU fallback in this package.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprhf.so")
+
+OK, EINVAL, ENEGDEN, EPEAK0, EHIP, ENOMEM = 0, -1, -2, -3, -4, -5
+MODE_O, MODE_X = 0, 1
+FLAG_DEVICE_PTRS, FLAG_ASYNC = 0x1, 0x2
+MATH_FAITHFUL, MATH_FAST = 0, 1
+ABI_VERSION = 1
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class Segment(ctypes.Structure):
+    """``prhf_segment`` of include/prhf.h."""
+    _fields_ = [("prof_begin", ctypes.c_int64), ("prof_end", ctypes.c_int64),
+                ("mode", ctypes.c_int32), ("n_points", ctypes.c_int32),
+                ("mult_offset", ctypes.c_int64), ("out_offset", ctypes.c_int64)]
+
+
+class NativeLibraryError(RuntimeError):
+    """libprhf.so is missing, stale, or the HIP runtime failed."""
+
+
+# every symbol include/prhf.h declares: name -> (restype, argtypes)
+_PROTOTYPES = {
+    "prhf_abi_version": (ctypes.c_int, []),
+    "prhf_last_error": (ctypes.c_char_p, []),
+    "prhf_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "prhf_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "prhf_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "prhf_ctx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "prhf_ctx_set_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "prhf_vfo_batch_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]),
+    "prhf_vfo_worklist_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.POINTER(Segment), ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]),
+    "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "prhf_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load libprhf.so once and attach prototypes; raise NativeLibraryError if unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pyrayhf_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in _PROTOTYPES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
+            fn.restype = res
+            fn.argtypes = args
+        if lib.prhf_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(f"ABI version {lib.prhf_abi_version()} != {ABI_VERSION}; rebuild libprhf.so")
+        _lib = lib
+        return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def last_error():
+    msg = load().prhf_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def raise_for(code):
+    """Map a PRHF_E* code to the exception the reference raises for the same condition."""
+    if code == OK:
+        return
+    msg = last_error()
+    if code == ENEGDEN:
+        raise ValueError("Density must be non-negative")          # reference library.py:93-94
+    if code == EPEAK0:
+        raise IndexError(msg or "density peak at index 0")         # the reference fails with IndexError too
+    if code == EINVAL:
+        raise ValueError(msg or "invalid argument")
+    if code == ENOMEM:
+        raise MemoryError(msg)
+    raise NativeLibraryError(msg or f"libprhf error {code}")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    raise_for(load().prhf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class Context:
+    """Owns one ``prhf_ctx`` (one device, one stream, scratch buffers)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        raise_for(self._lib.prhf_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.prhf_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def set_stream(self, stream_ptr):
+        raise_for(self._lib.prhf_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+
+    def set_math(self, level):
+        raise_for(self._lib.prhf_ctx_set_math(self._h, int(level)))
+
+    def vfo_batch(self, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride, alt_stride,
+                  mult, n_points, mode, out, flags):
+        """All array arguments are raw addresses (ints)."""
+        return self._lib.prhf_vfo_batch_f64(self._h, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt,
+                                            prof_stride, alt_stride, mult, n_points, mode, out, flags)
+
+    def vfo_worklist(self, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride, alt_stride,
+                     mult, mult_len, segments, out, flags):
+        arr = (Segment * len(segments))(*segments)
+        return self._lib.prhf_vfo_worklist_f64(self._h, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt,
+                                               prof_stride, alt_stride, mult, mult_len, arr, len(segments),
+                                               out, flags)
+
+    def sync(self):
+        return self._lib.prhf_sync(self._h)
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double(0.0)
+        raise_for(self._lib.prhf_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+
+_tls = threading.local()
+
+
+def default_device():
+    for key in ("PRHF_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(key, "") != "":
+            return int(os.environ[key])
+    return 0
+
+
+def context(device=None):
+    """Per-thread, per-device cached context."""
+    dev = default_device() if device is None else int(device)
+    cache = getattr(_tls, "ctx", None)
+    if cache is None:
+        cache = _tls.ctx = {}
+    ctx = cache.get(dev)
+    if ctx is None:
+        ctx = cache[dev] = Context(dev)
+    return ctx

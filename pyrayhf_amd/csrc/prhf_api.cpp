@@ -1,0 +1,354 @@
+// prhf_api.cpp - the C ABI of libprhf.so (include/prhf.h): contexts, launch planning,
+// host<->device staging, timing and error reporting.  No compute happens on the host;
+// there is no CPU fallback: without a GPU every compute entry point fails with PRHF_EHIP.
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "prhf.h"
+#include "prhf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(PRHF_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr long long kTargetWaves = 8192;   // ~1.3x the waves resident at 3 blocks per CU
+constexpr long long kMaxAlt = 2400;        // nodes + hints must fit 160 KiB of LDS
+constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct prhf_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int math = PRHF_MATH_FAITHFUL;
+    DevBuf arena;     // staged host inputs + output
+    DevBuf partial;   // chunk sums
+    DevBuf altmin;    // per-profile min(alt) for chunked slices
+    unsigned* d_status = nullptr;
+    unsigned* h_status = nullptr;   // pinned
+    bool status_pending = false;
+};
+
+namespace {
+
+int ensure(prhf_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return PRHF_OK;
+    if (b.p) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(PRHF_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PRHF_OK;
+}
+
+// Decompose one slice into wave-sized items and blocks ("Launch geometry").
+void plan_slice(prhf::SegDev& s, long long n_freq) {
+    const long long P = s.prof_end - s.prof_begin;
+    const long long pairs = P * n_freq;
+    const long long N = s.n_points;
+    long long chunks = 1, chunk_len = ((N + 63) / 64) * 64;
+    if (pairs > 0 && pairs < kTargetWaves && N > 256) {
+        long long want = std::min((kTargetWaves + pairs - 1) / pairs, (N + 255) / 256);
+        chunk_len = (((N + want - 1) / want + 63) / 64) * 64;
+        chunks = (N + chunk_len - 1) / chunk_len;
+    }
+    s.chunks = (int)chunks;
+    s.chunk_len = (int)chunk_len;
+    const long long items = n_freq * chunks;
+    long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
+                                                                 std::max<long long>(P, 1)));
+    s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+
+int status_to_code(unsigned bits) {
+    if (bits & PRHF_STATUS_PEAK0)
+        return fail(PRHF_EPEAK0, "density peak at index 0: no bottomside levels below the peak");
+    if (bits & PRHF_STATUS_NEGDEN) return fail(PRHF_ENEGDEN, "Density must be non-negative");
+    return PRHF_OK;
+}
+
+int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, const double* bmag,
+        const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt, int64_t prof_stride,
+        int64_t alt_stride, const double* mult, int64_t mult_len, const prhf_segment* segs, int32_t n_segs,
+        double* out, uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!freq || !den || !bmag || !bpsi || !alt || !mult || !out || !segs)
+        return fail(PRHF_EINVAL, "null array pointer");
+    if (n_freq < 1 || n_prof < 0 || n_alt < 1) return fail(PRHF_EINVAL, "bad shape");
+    if (n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt %lld exceeds the LDS-resident limit %lld",
+                                     (long long)n_alt, kMaxAlt);
+    if (n_freq > (1 << 20)) return fail(PRHF_EINVAL, "n_freq too large");
+    if (prof_stride < n_alt || (alt_stride != 0 && alt_stride < n_alt))
+        return fail(PRHF_EINVAL, "row stride shorter than a row");
+    if (n_segs < 1 || n_segs > PRHF_MAX_SEGMENTS)
+        return fail(PRHF_EINVAL, "1..%d segments per launch", PRHF_MAX_SEGMENTS);
+    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC)) return fail(PRHF_EINVAL, "unknown flag bits");
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    if ((flags & PRHF_FLAG_ASYNC) && !dev) return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC needs device pointers");
+
+    HIP_TRY(hipSetDevice(c->device));
+
+    prhf::KArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_freq = n_freq;
+    a.n_alt = n_alt;
+    a.n_segs = n_segs;
+    long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const prhf_segment& u = segs[i];
+        if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
+            return fail(PRHF_EINVAL, "segment %d: profile range outside [0, n_prof]", i);
+        if (u.mode != PRHF_MODE_O && u.mode != PRHF_MODE_X)
+            return fail(PRHF_EINVAL, "mode must be 'O' or 'X'");
+        if (u.n_points < 1) return fail(PRHF_EINVAL, "n_points must be >= 1");
+        if (u.mult_offset < 0 || u.mult_offset + u.n_points > mult_len)
+            return fail(PRHF_EINVAL, "segment %d: multiplier range outside the array", i);
+        if (u.out_offset < 0) return fail(PRHF_EINVAL, "segment %d: negative output offset", i);
+        prhf::SegDev& s = a.seg[i];
+        s.prof_begin = u.prof_begin;
+        s.prof_end = u.prof_end;
+        s.mult_off = u.mult_offset;
+        s.out_off = u.out_offset;
+        s.mode = u.mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
+        s.n_points = u.n_points;
+        plan_slice(s, n_freq);
+        s.block_begin = blocks;
+        const long long P = u.prof_end - u.prof_begin;
+        blocks += P * s.blocks_per_prof;
+        if (s.chunks > 1) {
+            s.partial_off = partial_elems;
+            s.altmin_off = altmin_elems;
+            partial_elems += P * n_freq * s.chunks;
+            altmin_elems += P;
+        }
+        out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + P);
+    }
+    if (blocks > 0x7fffffffLL) return fail(PRHF_EINVAL, "launch too large");
+
+    int rc;
+    if ((rc = ensure(c, c->partial, (size_t)partial_elems * 8)) != PRHF_OK) return rc;
+    if ((rc = ensure(c, c->altmin, (size_t)altmin_elems * 8)) != PRHF_OK) return rc;
+    a.partial = static_cast<double*>(c->partial.p);
+    a.altmin = static_cast<double*>(c->altmin.p);
+    a.status = c->d_status;
+
+    const size_t row_bytes = (size_t)n_alt * 8;
+    double* d_out = nullptr;
+    const size_t out_elems = (size_t)out_rows * (size_t)n_freq;
+    if (dev) {
+        a.freq = freq; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = mult;
+        a.out = out;
+        a.prof_stride = prof_stride;
+        a.alt_stride = alt_stride;
+    } else {
+        const size_t n_alt_rows = alt_stride ? (size_t)n_prof : 1;
+        const size_t elems = (size_t)n_freq + 3 * (size_t)n_prof * n_alt + n_alt_rows * n_alt +
+                             (size_t)mult_len + out_elems;
+        if ((rc = ensure(c, c->arena, elems * 8)) != PRHF_OK) return rc;
+        double* base = static_cast<double*>(c->arena.p);
+        double* d_freq = base;
+        double* d_den = d_freq + n_freq;
+        double* d_bmag = d_den + (size_t)n_prof * n_alt;
+        double* d_bpsi = d_bmag + (size_t)n_prof * n_alt;
+        double* d_alt = d_bpsi + (size_t)n_prof * n_alt;
+        double* d_mult = d_alt + n_alt_rows * n_alt;
+        d_out = d_mult + mult_len;
+        HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
+        if (n_prof > 0) {
+            HIP_TRY(hipMemcpy2DAsync(d_den, row_bytes, den, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                     hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpy2DAsync(d_bmag, row_bytes, bmag, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                     hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpy2DAsync(d_bpsi, row_bytes, bpsi, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                     hipMemcpyHostToDevice, c->stream));
+        }
+        if (alt_stride) {
+            if (n_prof > 0)
+                HIP_TRY(hipMemcpy2DAsync(d_alt, row_bytes, alt, (size_t)alt_stride * 8, row_bytes, (size_t)n_prof,
+                                         hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_alt, alt, row_bytes, hipMemcpyHostToDevice, c->stream));
+        }
+        a.freq = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.mult = d_mult;
+        a.out = d_out;
+        a.prof_stride = n_alt;
+        a.alt_stride = alt_stride ? n_alt : 0;
+    }
+
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_vfo(a, blocks, c->math == PRHF_MATH_FAST ? 1 : 0, prhf::lds_bytes_for(n_alt), c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    c->status_pending = true;
+
+    if (!dev && out_elems)
+        HIP_TRY(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
+    if (flags & PRHF_FLAG_ASYNC) return PRHF_OK;
+    return prhf_sync(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int prhf_abi_version(void) { return PRHF_ABI_VERSION; }
+
+const char* prhf_last_error(void) { return g_err.c_str(); }
+
+int prhf_device_count(int* n) {
+    if (!n) return fail(PRHF_EINVAL, "null pointer");
+    *n = 0;
+    HIP_TRY(hipGetDeviceCount(n));
+    return PRHF_OK;
+}
+
+int prhf_ctx_create(int device, prhf_ctx** out) {
+    if (!out) return fail(PRHF_EINVAL, "null pointer");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(PRHF_EINVAL, "device %d not in [0, %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    prhf_ctx* c = new (std::nothrow) prhf_ctx;
+    if (!c) return fail(PRHF_ENOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), sizeof(unsigned))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
+            hipSuccess ||
+        (e = hipMemset(c->d_status, 0, sizeof(unsigned))) != hipSuccess ||
+        (e = prhf::configure_kernels(prhf::lds_bytes_for(kMaxAlt))) != hipSuccess) {
+        prhf_ctx_destroy(c);
+        return fail(PRHF_EHIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return PRHF_OK;
+}
+
+int prhf_ctx_destroy(prhf_ctx* c) {
+    if (!c) return PRHF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->arena.p) (void)hipFree(c->arena.p);
+    if (c->partial.p) (void)hipFree(c->partial.p);
+    if (c->altmin.p) (void)hipFree(c->altmin.p);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PRHF_OK;
+}
+
+int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return PRHF_OK;
+}
+
+int prhf_ctx_set_math(prhf_ctx* c, int level) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (level != PRHF_MATH_FAITHFUL && level != PRHF_MATH_FAST) return fail(PRHF_EINVAL, "unknown math tier");
+    c->math = level;
+    return PRHF_OK;
+}
+
+int prhf_vfo_batch_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq, const double* den,
+                       const double* bmag, const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                       int64_t prof_stride_elems, int64_t alt_stride_elems, const double* multiplier,
+                       int32_t n_points, int32_t mode, double* vh_out, uint32_t flags) {
+    prhf_segment seg;
+    seg.prof_begin = 0;
+    seg.prof_end = n_prof;
+    seg.mode = mode;
+    seg.n_points = n_points;
+    seg.mult_offset = 0;
+    seg.out_offset = 0;
+    return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
+               multiplier, n_points, &seg, 1, vh_out, flags);
+}
+
+int prhf_vfo_worklist_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq, const double* den,
+                          const double* bmag, const double* bpsi, const double* alt, int64_t n_prof,
+                          int64_t n_alt, int64_t prof_stride_elems, int64_t alt_stride_elems,
+                          const double* multiplier, int64_t multiplier_len, const prhf_segment* segs,
+                          int32_t n_segs, double* vh_out, uint32_t flags) {
+    return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
+               multiplier, multiplier_len, segs, n_segs, vh_out, flags);
+}
+
+int prhf_sync(prhf_ctx* c) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->status_pending) {
+        HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(unsigned), c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->status_pending) {
+        c->status_pending = false;
+        return status_to_code(*c->h_status);
+    }
+    return PRHF_OK;
+}
+
+int prhf_last_kernel_ms(prhf_ctx* c, double* ms) {
+    if (!c || !ms) return fail(PRHF_EINVAL, "null pointer");
+    if (!c->timed) return fail(PRHF_EINVAL, "no launch has been timed on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    *ms = t;
+    return PRHF_OK;
+}
+
+}  // extern "C"

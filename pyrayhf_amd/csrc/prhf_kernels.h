@@ -1,0 +1,62 @@
+// prhf_kernels.h - launch interface between the C ABI (prhf_api.cpp) and the HIP kernels.
+#ifndef PRHF_KERNELS_H
+#define PRHF_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define PRHF_KMODE_O 0
+#define PRHF_KMODE_X 1
+
+#define PRHF_STATUS_NEGDEN 0x1
+#define PRHF_STATUS_PEAK0  0x2
+
+#define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
+#define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
+#define PRHF_MAX_SEGMENTS 8
+#define PRHF_RED_DOUBLES 64         // block-reduction scratch (6 * waves, rounded up)
+
+namespace prhf {
+
+// One homogeneous slice of a launch, with its decomposition into blocks.
+struct SegDev {
+    long long prof_begin, prof_end;  // profile rows [begin, end)
+    long long mult_off;              // first element of this slice's multiplier grid
+    long long out_off;               // first element of this slice's output rows
+    long long block_begin;           // first block index of this slice
+    long long partial_off;           // chunk-sum scratch offset (chunks > 1)
+    long long altmin_off;            // per-profile min(alt) scratch offset (chunks > 1)
+    int mode, n_points;
+    int chunks;                      // wave-sized work items per pair
+    int chunk_len;                   // grid points per chunk (multiple of 64)
+    int blocks_per_prof;
+    int pad_;
+};
+
+struct KArgs {
+    const double* freq;
+    const double* den;
+    const double* bmag;
+    const double* bpsi;
+    const double* alt;
+    const double* mult;
+    double* out;
+    double* partial;
+    double* altmin;
+    unsigned* status;
+    long long n_freq, n_alt, prof_stride, alt_stride;
+    int n_segs;
+    SegDev seg[PRHF_MAX_SEGMENTS];
+};
+
+inline size_t lds_bytes_for(long long n_alt) {
+    return (size_t)n_alt * 64 + PRHF_HINT_BUCKETS * 2 + PRHF_RED_DOUBLES * 8;
+}
+
+hipError_t configure_kernels(size_t max_lds_bytes);
+hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
+
+}  // namespace prhf
+
+#endif

@@ -1,0 +1,261 @@
+"""Drop-in for the reference's vertical-ionogram forward operator, on MI355X.
+
+``vertical_forward_operator`` has the signature, positional order, units, output shape and
+error behaviour of ``PyRayHF.library.vertical_forward_operator`` (reference
+``PyRayHF/library.py:459-509``); the arithmetic runs in libprhf.so's fused HIP kernel
+(``pyrayhf_amd/csrc/prhf_kernels.hip``).  Extensions that the reference does not have:
+
+* ``den/bmag/bpsi`` may be 2-D ``(P, N_alt)`` (``alt`` shared 1-D or 2-D): the result is
+  ``(P, F)`` and equals a Python loop of single-profile calls;
+* inputs may be ``torch`` tensors resident on the GPU (zero-copy, result is a tensor);
+* ``vertical_forward_operator_mixed`` evaluates slices with different mode / n_points
+  in one launch (BASELINE config 5).
+
+The tiny host-side helpers of the path (constants, unit conversions, the stretched unit
+grid) are provided under the reference's names so that callers can switch imports.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native, logger
+
+__all__ = [
+    "constants", "den2freq", "freq2den", "find_X", "find_Y", "smooth_nonuniform_grid",
+    "vertical_to_magnetic_angle", "vertical_forward_operator", "vertical_forward_operator_mixed",
+    "last_kernel_ms",
+]
+
+
+# ----------------------------------------------------------------------------------------
+# host helpers (reference library.py:40-158, :296-321, :441-456); closed-form, O(N) or less
+# ----------------------------------------------------------------------------------------
+def constants():
+    """(cp [Hz m^1.5], g_p [Hz/T], R_E [km], c [km/s]); reference library.py:40-72."""
+    return 8.97866275, 2.799249247e10, 6371.0, 299_792.458
+
+
+def den2freq(density):
+    """Plasma frequency [Hz] of an electron density [m^-3]; reference library.py:75-97."""
+    cp = constants()[0]
+    if np.any(np.asarray(density) < 0):
+        raise ValueError("Density must be non-negative")
+    return np.sqrt(density) * cp
+
+
+def freq2den(frequency):
+    """Electron density [m^-3] of a plasma frequency [Hz]; reference library.py:100-117."""
+    cp = constants()[0]
+    return (frequency / cp) ** 2
+
+
+def find_X(n_e, f):
+    """X = (f_N / f)^2; reference library.py:120-137."""
+    return den2freq(n_e) ** 2 / f ** 2
+
+
+def find_Y(f, b):
+    """Y = f_H / f; reference library.py:140-158."""
+    g_p = constants()[1]
+    return g_p * b / f
+
+
+def smooth_nonuniform_grid(start, end, n_points, sharpness):
+    """Monotone grid from 0 to 1 that is dense near 1; reference library.py:296-321.
+
+    (As in the reference, ``start``/``end`` only scale the exponential factor; the operator
+    calls it with 0, 1, n_points, 10.)
+    """
+    u = np.linspace(0.0, 1.0, n_points)
+    factor = (np.exp(sharpness * (1.0 - u)) - 1.0) / (np.exp(sharpness) - 1.0)
+    return 1.0 - (start + (end - start) * factor)
+
+
+def vertical_to_magnetic_angle(inclination_deg):
+    """Angle between the vertical and the field; reference library.py:441-456."""
+    return 90.0 - np.abs(inclination_deg)
+
+
+# ----------------------------------------------------------------------------------------
+# the operator
+# ----------------------------------------------------------------------------------------
+_MODE_CODE = {"O": _native.MODE_O, "X": _native.MODE_X}
+_mult_cache = {}
+
+
+def _mode_code(mode):
+    try:
+        return _MODE_CODE[mode]
+    except (KeyError, TypeError):
+        raise ValueError("mode must be 'O' or 'X'") from None     # reference library.py:395-396
+
+
+def _multiplier(n_points):
+    n = int(n_points)
+    if n < 1:
+        raise ValueError("n_points must be >= 1")
+    m = _mult_cache.get(n)
+    if m is None:
+        with np.errstate(all="ignore"):
+            m = np.ascontiguousarray(smooth_nonuniform_grid(0, 1, n, 10.0), dtype=np.float64)
+        if len(_mult_cache) > 32:
+            _mult_cache.clear()
+        _mult_cache[n] = m
+    return m
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+def _as_rows(name, x):
+    a = np.ascontiguousarray(np.asarray(x), dtype=np.float64)
+    if a.ndim == 0 or a.ndim > 2:
+        raise ValueError(f"{name} must be 1-D (one profile) or 2-D (profiles x levels)")
+    return a
+
+
+def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
+    f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
+    if f.ndim != 1:
+        raise ValueError("freq must be a scalar or 1-D")
+    d, b, p, a = (_as_rows(n, x) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi), ("alt", alt)))
+    single = d.ndim == 1
+    d2, b2, p2 = (np.atleast_2d(x) for x in (d, b, p))
+    if not (d2.shape == b2.shape == p2.shape):
+        logger.error("Error: freq, den, bmag, bpsi, alt should have same size")   # reference library.py:487-488
+        raise ValueError("den, bmag and bpsi must have the same shape")
+    n_prof, n_alt = d2.shape
+    if a.shape[-1] != n_alt or (a.ndim == 2 and a.shape[0] != n_prof):
+        logger.error("Error: freq, den, bmag, bpsi, alt should have same size")
+        raise ValueError("alt must have one value per density level")
+    alt_stride = n_alt if a.ndim == 2 else 0
+    mult = _multiplier(n_points)
+    out = np.empty((n_prof, f.size), dtype=np.float64)
+    ctx = _native.context(device)
+    if math is not None:
+        ctx.set_math(math)
+    rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
+                       n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
+                       out.ctypes.data, 0)
+    _native.raise_for(rc)
+    return out[0] if single else out
+
+
+def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync, out):
+    import torch
+
+    dev = den.device
+    if dev.type != "cuda":
+        raise ValueError("torch inputs must live on the GPU; pass NumPy arrays for host data")
+
+    def prep(x, name):
+        if not _is_torch(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev)
+        if x.device != dev:
+            raise ValueError(f"{name} is on {x.device}, expected {dev}")
+        return x.to(torch.float64).contiguous()
+
+    f = prep(freq, "freq").reshape(-1)
+    d, b, p, a = (prep(x, n) for x, n in ((den, "den"), (bmag, "bmag"), (bpsi, "bpsi"), (alt, "alt")))
+    single = d.dim() == 1
+    d2, b2, p2 = (x.reshape(1, -1) if x.dim() == 1 else x for x in (d, b, p))
+    if not (d2.shape == b2.shape == p2.shape) or d2.dim() != 2:
+        raise ValueError("den, bmag and bpsi must have the same 1-D or 2-D shape")
+    n_prof, n_alt = d2.shape
+    if a.shape[-1] != n_alt or (a.dim() == 2 and a.shape[0] != n_prof):
+        raise ValueError("alt must have one value per density level")
+    alt_stride = n_alt if a.dim() == 2 else 0
+    key = (int(n_points), dev.index)
+    mult = _torch_mult.get(key)
+    if mult is None:
+        mult = _torch_mult[key] = torch.as_tensor(_multiplier(n_points), device=dev)
+    if out is None:
+        out = torch.empty((n_prof, f.numel()), dtype=torch.float64, device=dev)
+    elif out.shape != (n_prof, f.numel()) or out.dtype != torch.float64 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float64 tensor of shape (P, F)")
+    ctx = _native.context(dev.index if dev.index is not None else torch.cuda.current_device())
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    if math is not None:
+        ctx.set_math(math)
+    rc = ctx.vfo_batch(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
+                       n_prof, n_alt, n_alt, alt_stride, mult.data_ptr(), int(n_points), mode_code,
+                       out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC)
+    _native.raise_for(rc)
+    if sync:
+        _native.raise_for(ctx.sync())
+    return out[0] if single else out
+
+
+_torch_mult = {}
+
+
+def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200, *,
+                              device=None, math=None, sync=True, out=None):
+    """Virtual height [km] of each sounder frequency for one profile (or a batch).
+
+    Parameters are the reference's (library.py:459-484): ``freq`` MHz, ``den`` m^-3,
+    ``bmag`` Tesla, ``bpsi`` degrees, ``alt`` km (ascending), ``mode`` 'O' or 'X',
+    ``n_points`` stretched-grid points per frequency.  Returns ``ndarray (F,)`` for 1-D
+    profiles (a scalar ``freq`` gives shape (1,)), ``(P, F)`` for 2-D ones; NaN where the
+    frequency is not reflected below the density peak.
+
+    Keyword-only extensions: ``device`` (GPU index for host inputs; default ``PRHF_DEVICE``
+    / ``LOCAL_RANK`` / 0), ``math`` (``pyrayhf_amd.MATH_FAITHFUL`` / ``MATH_FAST``),
+    and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
+
+    Raises ``ValueError("mode must be 'O' or 'X'")``, ``ValueError("Density must be
+    non-negative")`` (reference library.py:395-396, :93-94), ``IndexError`` when the density
+    peak is the first level (the reference fails with IndexError there too), and
+    ``ValueError`` on shape mismatch (the reference only logs, library.py:487-488).
+    """
+    code = _mode_code(mode)
+    if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):
+        return _torch_operator(freq, den, bmag, bpsi, alt, code, n_points, math, sync, out)
+    return _np_operator(freq, den, bmag, bpsi, alt, code, n_points, device, math)
+
+
+def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, device=None, math=None):
+    """Several (profile range, mode, n_points) slices in ONE launch (BASELINE config 5).
+
+    ``segments`` is a sequence of ``(prof_begin, prof_end, mode, n_points)``; profile ranges
+    index the rows of the 2-D inputs.  Returns ``(P, F)`` float64 (host inputs only); rows not
+    covered by any segment are NaN.
+    """
+    f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
+    d2, b2, p2 = (np.atleast_2d(_as_rows(n, x)) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi)))
+    a = _as_rows("alt", alt)
+    if not (d2.shape == b2.shape == p2.shape):
+        raise ValueError("den, bmag and bpsi must have the same shape")
+    n_prof, n_alt = d2.shape
+    if a.shape[-1] != n_alt or (a.ndim == 2 and a.shape[0] != n_prof):
+        raise ValueError("alt must have one value per density level")
+    segs, grids, off = [], [], 0
+    for (p0, p1, mode, n_points) in segments:
+        m = _multiplier(n_points)
+        segs.append(_native.Segment(int(p0), int(p1), _mode_code(mode), int(n_points), off, int(p0) * f.size))
+        grids.append(m)
+        off += m.size
+    mult = np.ascontiguousarray(np.concatenate(grids)) if grids else np.zeros(1)
+    out = np.full((n_prof, f.size), np.nan, dtype=np.float64)
+    if not segs:
+        return out
+    ctx = _native.context(device)
+    if math is not None:
+        ctx.set_math(math)
+    # the library writes only the rows its segments cover: stage `out` through the call
+    rc = ctx.vfo_worklist(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
+                          n_prof, n_alt, n_alt, n_alt if a.ndim == 2 else 0, mult.ctypes.data, mult.size,
+                          segs, out.ctypes.data, 0)
+    _native.raise_for(rc)
+    covered = np.zeros(n_prof, dtype=bool)
+    for s in segs:
+        covered[s.prof_begin:s.prof_end] = True
+    out[~covered] = np.nan
+    return out
+
+
+def last_kernel_ms(device=None):
+    """Device time [ms] of the most recent launch on this thread's context."""
+    return _native.context(device).last_kernel_ms()

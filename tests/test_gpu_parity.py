@@ -1,0 +1,164 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the committed golden
+vectors of the reference and against the oracle on seeded inputs.  Run with -m gpu."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from parity import assert_masks, assert_o_mode, assert_x_mode, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pyrayhf_amd import library
+    return library
+
+
+def test_basic_operator_g1(lib):
+    g = load_golden("g1_basic.npz")
+    # reference test_core.py:223-236 (alt is an int array there)
+    vh = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"].astype(int),
+                                       mode="O", n_points=int(g["n_points"]))
+    assert isinstance(vh, np.ndarray) and vh.shape == g["freq"].shape
+    assert np.isnan(vh[-1]) and np.all(np.isfinite(vh[:-1]))
+    assert_o_mode(vh, g["vh_O"])
+    vx = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", int(g["n_points"]))
+    assert_x_mode(vx, g["vh_X"])
+
+
+def test_edp_known_answer_g2(lib):
+    g = load_golden("g2_edp_kat.npz")
+    vh = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"])   # defaults O/200
+    np.testing.assert_allclose(vh, g["vh_published"], rtol=1e-6)      # reference test_core.py:275
+    assert_o_mode(vh, g["vh_O"])
+
+
+def test_scalar_frequency_gives_shape_1(lib):
+    g = load_golden("g1_basic.npz")
+    vh = lib.vertical_forward_operator(np.float64(2.0), g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 50)
+    assert vh.shape == (1,)
+    assert abs(vh[0] - g["vh_O"][1]) <= 1e-6 * g["vh_O"][1]
+
+
+@pytest.mark.parametrize("which", ["Day", "Night"])
+@pytest.mark.parametrize("n_points", [200, 2000, 20000])
+def test_day_night_x_mode_g4(lib, which, n_points):
+    g = load_golden("g4_day_night.npz")
+    vh = lib.vertical_forward_operator(g["freq"], g[f"{which}_den"], g[f"{which}_bmag"], g[f"{which}_bpsi"],
+                                       g[f"{which}_alt"], "X", n_points)
+    worst = assert_x_mode(vh, g[f"{which}_X_{n_points}_vh"])
+    print(f"{which} X n={n_points}: max rel err {worst:.3e}")
+
+
+@pytest.mark.parametrize("which", ["Day", "Night"])
+@pytest.mark.parametrize("n_points", [200, 2000, 20000])
+def test_day_night_o_mode_g4(lib, which, n_points):
+    g = load_golden("g4_day_night.npz")
+    vh = lib.vertical_forward_operator(g["freq"], g[f"{which}_den"], g[f"{which}_bmag"], g[f"{which}_bpsi"],
+                                       g[f"{which}_alt"], "O", n_points)
+    want, noise = g[f"{which}_O_{n_points}_vh"], g[f"{which}_O_{n_points}_noise"]
+    worst = assert_o_mode(vh, want, noise)
+    err, ok = rel_err(vh, want)
+    print(f"{which} O n={n_points}: max rel err {worst:.3e}; worst err/noise "
+          f"{np.max(err[ok] / np.maximum(noise[ok], 1e-16)):.2f}; within 1e-6: {(err[ok] <= 1e-6).mean():.3f}")
+
+
+def test_chapman_batch_g5(lib):
+    g = load_golden("g5_chapman64.npz")
+    vo = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 200)
+    assert vo.shape == (64, g["freq"].size)
+    assert_o_mode(vo, g["O_200_vh"], g["O_200_noise"])
+    vx = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000)
+    assert_x_mode(vx, g["X_2000_vh"])
+    # batch == loop of single-profile calls, bit for bit
+    one = lib.vertical_forward_operator(g["freq"], g["den"][5], g["bmag"][5], g["bpsi"][5], g["alt"], "X", 2000)
+    assert np.array_equal(one, vx[5], equal_nan=True)
+
+
+def test_edge_cases_g7(lib):
+    g = load_golden("g7_edges.npz")
+    names = sorted({k[: -len("_n_points")] for k in g if k.endswith("_n_points")})
+    for name in names:
+        args = [g[f"{name}_{k}"] for k in ("freq", "den", "bmag", "bpsi", "alt")]
+        n = int(g[f"{name}_n_points"])
+        for mode in "OX":
+            vh = lib.vertical_forward_operator(*args, mode, n)
+            want = g[f"{name}_vh_{mode}"]
+            assert_masks(vh, want)
+            err, ok = rel_err(vh, want)
+            assert err.max(initial=0.0) <= 2e-6, (name, mode, err.max())
+
+
+def test_error_behaviour(lib):
+    g = load_golden("g1_basic.npz")
+    args = (g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"])
+    with pytest.raises(ValueError, match="mode must be 'O' or 'X'"):
+        lib.vertical_forward_operator(*args, "Z", 10)
+    neg = g["den"].copy()
+    neg[1] = -1.0
+    with pytest.raises(ValueError, match="Density must be non-negative"):
+        lib.vertical_forward_operator(g["freq"], neg, g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    with pytest.raises(IndexError):
+        lib.vertical_forward_operator(g["freq"], g["den"][::-1].copy(), g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    with pytest.raises(ValueError):
+        lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    # the context stays usable after a data error
+    vh = lib.vertical_forward_operator(*args, "O", 50)
+    assert np.isfinite(vh[0])
+
+
+def test_inputs_are_not_mutated(lib):
+    g = load_golden("g1_basic.npz")
+    args = [g[k].copy() for k in ("freq", "den", "bmag", "bpsi", "alt")]
+    before = [a.copy() for a in args]
+    lib.vertical_forward_operator(*args, "X", 50)
+    for a, b in zip(args, before):
+        assert np.array_equal(a, b)
+
+
+def test_oracle_on_fresh_seeded_batch(lib):
+    """Seeded inputs never seen by the fixtures: HIP vs the oracle at oracle-friendly sizes."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(24, 4242)
+    freq = synth.sounder_frequencies(4)
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 2000)
+    want = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", 2000)
+    assert_x_mode(got, want)
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 200)
+    want = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", 200)
+    assert_masks(got, want)
+    err, ok = rel_err(got, want)
+    assert np.mean(err[ok] <= 1e-6) >= 0.95 and err.max() <= 2e-4
+
+
+def test_per_profile_altitude_rows(lib):
+    g = load_golden("g5_chapman64.npz")
+    alt2 = np.tile(g["alt"], (8, 1))
+    a = lib.vertical_forward_operator(g["freq"], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], alt2, "X", 400)
+    b = lib.vertical_forward_operator(g["freq"], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 400)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_mixed_worklist_matches_separate_launches(lib):
+    g = load_golden("g5_chapman64.npz")
+    args = (g["freq"], g["den"][:24], g["bmag"][:24], g["bpsi"][:24], g["alt"])
+    segs = [(0, 8, "O", 200), (8, 14, "X", 2000), (14, 20, "O", 2000), (20, 24, "X", 20000)]
+    mixed = lib.vertical_forward_operator_mixed(*args, segs)
+    for p0, p1, mode, n in segs:
+        sep = lib.vertical_forward_operator(g["freq"], g["den"][p0:p1], g["bmag"][p0:p1], g["bpsi"][p0:p1],
+                                            g["alt"], mode, n)
+        assert np.array_equal(mixed[p0:p1], sep, equal_nan=True), (p0, p1, mode, n)
+
+
+def test_torch_device_resident_inputs(lib):
+    import torch
+    g = load_golden("g5_chapman64.npz")
+    dev = torch.device("cuda:0")
+    t = {k: torch.as_tensor(g[k], device=dev) for k in ("freq", "den", "bmag", "bpsi", "alt")}
+    out = lib.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", 2000)
+    assert out.is_cuda and out.shape == (64, g["freq"].size)
+    host = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000)
+    assert np.array_equal(out.cpu().numpy(), host, equal_nan=True)
