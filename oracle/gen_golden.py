@@ -40,7 +40,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 REF = "/root/reference"
 OUT = os.path.join(REPO, "tests", "golden")
-NOISE_RUNS = 8
+NOISE_RUNS = 24
 
 
 def load_reference_library():

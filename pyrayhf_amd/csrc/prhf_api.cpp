@@ -288,9 +288,11 @@ int prhf_ctx_destroy(prhf_ctx* c) {
 
 int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream) {
     if (!c) return fail(PRHF_EINVAL, "null context");
+    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    if (next == c->stream) return PRHF_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // scratch buffers are reused across launches
+    c->stream = next;
     return PRHF_OK;
 }
 

@@ -21,10 +21,12 @@ def _chapman(nm, hm, scale_h, alt):
     return nm[:, None] * np.exp(0.5 * (1.0 - z - np.exp(-z)))
 
 
-def chapman_profiles(n_profiles, seed):
+def chapman_profiles(n_profiles, seed, rows=None):
     """Return ``(alt (N_alt,), den, bmag, bpsi)`` with the last three ``(P, N_alt)``.
 
-    Units follow the operator: den m^-3, bmag Tesla, bpsi degrees, alt km.
+    Units follow the operator: den m^-3, bmag Tesla, bpsi degrees, alt km.  ``rows`` (a
+    slice) builds only those rows of the ``n_profiles`` batch - the layer parameters of the
+    whole batch are always drawn, so a shard equals the same rows of the full batch.
     """
     rng = np.random.default_rng(seed)
     p = int(n_profiles)
@@ -36,6 +38,9 @@ def chapman_profiles(n_profiles, seed):
     b0 = rng.uniform(2.2e-5, 6.0e-5, size=p)
     psi0 = rng.uniform(0.0, 89.0, size=p)
 
+    if rows is not None:
+        nmf2, hmf2, hf2, nme, he, b0, psi0 = (v[rows] for v in (nmf2, hmf2, hf2, nme, he, b0, psi0))
+        p = nmf2.size
     alt = ALT_KM.copy()
     den = _chapman(nmf2, hmf2, hf2, alt) + _chapman(nme, np.full(p, 110.0), he, alt)
     bmag = b0[:, None] * ((6371.0 + 80.0) / (6371.0 + alt[None, :])) ** 3
