@@ -117,6 +117,15 @@ int prhf_vfo_worklist_f64(prhf_ctx* ctx,
                           const prhf_segment* segs, int32_t n_segs,
                           double* vh_out, uint32_t flags);
 
+/*
+ * Appleton-Hartree phase index mu and group index mu' on flat arrays of n elements.
+ * Replaces: find_mu_mup (reference library.py:161-256); psi_deg in degrees.  As in the reference,
+ * the isotropic formulas are used when max|Y| over the whole array is below 1e-12 (:201-207).
+ * Synchronous (one device->host word decides the branch).
+ */
+int prhf_mu_mup_f64(prhf_ctx* ctx, const double* X, const double* Y, const double* psi_deg, int64_t n,
+                    int32_t mode, double* mu_out, double* mup_out, uint32_t flags);
+
 /* Wait for everything enqueued on the context; returns PRHF_ENEGDEN / PRHF_EPEAK0 if a
  * kernel flagged bad input since the last sync. */
 int prhf_sync(prhf_ctx* ctx);

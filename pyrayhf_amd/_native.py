@@ -51,6 +51,9 @@ _PROTOTYPES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_int64, ctypes.POINTER(Segment), ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32]),
+    "prhf_mu_mup_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_uint32]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "prhf_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
@@ -157,6 +160,9 @@ class Context:
         return self._lib.prhf_vfo_worklist_f64(self._h, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt,
                                                prof_stride, alt_stride, mult, mult_len, arr, len(segments),
                                                out, flags)
+
+    def mu_mup(self, X, Y, psi, n, mode, mu, mup, flags):
+        return self._lib.prhf_mu_mup_f64(self._h, X, Y, psi, n, mode, mu, mup, flags)
 
     def sync(self):
         return self._lib.prhf_sync(self._h)

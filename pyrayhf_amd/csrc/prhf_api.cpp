@@ -37,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr long long kTargetWaves = 8192;   // ~1.3x the waves resident at 3 blocks per CU
-constexpr long long kMaxAlt = 2400;        // nodes + hints must fit 160 KiB of LDS
+constexpr long long kMaxAlt = 2200;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
 struct DevBuf {
@@ -59,6 +59,8 @@ struct prhf_ctx {
     DevBuf altmin;    // per-profile min(alt) for chunked slices
     unsigned* d_status = nullptr;
     unsigned* h_status = nullptr;   // pinned
+    unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
+    unsigned long long* h_words = nullptr;   // pinned
     bool status_pending = false;
 };
 
@@ -261,6 +263,9 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
             hipSuccess ||
         (e = hipMemset(c->d_status, 0, sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_words), 2 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 2 * sizeof(unsigned long long),
+                           hipHostMallocDefault)) != hipSuccess ||
         (e = prhf::configure_kernels(prhf::lds_bytes_for(kMaxAlt))) != hipSuccess) {
         prhf_ctx_destroy(c);
         return fail(PRHF_EHIP, "context setup failed: %s", hipGetErrorString(e));
@@ -279,6 +284,8 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->altmin.p) (void)hipFree(c->altmin.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->d_words) (void)hipFree(c->d_words);
+    if (c->h_words) (void)hipHostFree(c->h_words);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -325,6 +332,41 @@ int prhf_vfo_worklist_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
                           int32_t n_segs, double* vh_out, uint32_t flags) {
     return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
                multiplier, multiplier_len, segs, n_segs, vh_out, flags);
+}
+
+int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double* psi_deg, int64_t n,
+                    int32_t mode, double* mu_out, double* mup_out, uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!X || !Y || !psi_deg || !mu_out || !mup_out) return fail(PRHF_EINVAL, "null array pointer");
+    if (n < 0) return fail(PRHF_EINVAL, "bad shape");
+    if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "Mode must be O or X");
+    if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
+    if (n == 0) return PRHF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    const double *dX = X, *dY = Y, *dP = psi_deg;
+    double *dMu = mu_out, *dMup = mup_out;
+    const size_t bytes = (size_t)n * 8;
+    if (!dev) {
+        int rc = ensure(c, c->arena, 5 * bytes);
+        if (rc != PRHF_OK) return rc;
+        double* base = static_cast<double*>(c->arena.p);
+        HIP_TRY(hipMemcpyAsync(base, X, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(base + n, Y, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(base + 2 * n, psi_deg, bytes, hipMemcpyHostToDevice, c->stream));
+        dX = base; dY = base + n; dP = base + 2 * n; dMu = base + 3 * n; dMup = base + 4 * n;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_mu_mup(dX, dY, dP, n, mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
+                                c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dMu, dMup, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(mu_out, dMu, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(mup_out, dMup, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PRHF_OK;
 }
 
 int prhf_sync(prhf_ctx* c) {

@@ -50,12 +50,17 @@ struct KArgs {
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 
+// nodes (64 B) + f_N^2 (8 B) per level, segment hints, block-reduction scratch
 inline size_t lds_bytes_for(long long n_alt) {
-    return (size_t)n_alt * 64 + PRHF_HINT_BUCKETS * 2 + PRHF_RED_DOUBLES * 8;
+    return (size_t)n_alt * 72 + PRHF_HINT_BUCKETS * 2 + PRHF_RED_DOUBLES * 8;
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes);
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
+// absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
+hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
+                         unsigned long long* absmax_scratch, unsigned long long* absmax_host,
+                         double* mu, double* mup, hipStream_t stream);
 
 }  // namespace prhf
 

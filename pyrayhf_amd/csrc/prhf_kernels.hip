@@ -2,15 +2,20 @@
 //
 // One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its
 // stretched grid when few pairs are submitted.  A workgroup shares one profile: its
-// bottomside columns are staged once into LDS as 64-byte nodes
-//     {alt, den, d(den)/dz, |B|, d|B|/dz, psi, d(psi)/dz, f_N^2}
-// so that every grid point costs four ds_read_b128 and no HBM traffic.  Per pair:
+// bottomside columns are staged once into LDS as 64-byte nodes, so that every grid point
+// costs four ds_read_b128 and no HBM traffic.  Per pair:
 //   S3-S6  reflection height: lanes stride over the levels, first level with X (or X+Y) > 1
 //          by ballot, running maximum below it by a wave max-reduce, np.interp semantics;
-//   S7-S10 lanes stride over the n_points stretched altitudes: locate the segment through
-//          an LDS hint table, interpolate den/|B|/psi linearly, Appleton-Hartree mu and mu';
+//   S7-S10 lanes stride over the n_points stretched altitudes: locate the segment (closed
+//          form on uniform grids, LDS hint table otherwise), interpolate den/|B|/psi
+//          linearly, Appleton-Hartree mu and mu';
 //   S11    left-rectangle sum of mu'*dh with NaNs skipped, wave sum-reduce, 0 -> NaN, + min(alt).
 // Stage names S0-S11 are SURVEY.md section 2.1; reference line numbers are PyRayHF/library.py.
+//
+// Two arithmetic tiers (DESIGN.md "Arithmetic tiers"):
+//   TIER 0 "faithful": the reference's operation order, IEEE divide and sqrt, no contraction;
+//   TIER 1 "fast":     shared reciprocals / rsqrt with Newton refinement, sin/cos of the
+//                      interpolated angle by rotation from node values, FMA contraction.
 //
 // No MFMA: the work is elementwise float64 transcendental + reduction ("Roofline").
 
@@ -23,14 +28,18 @@ namespace prhf {
 
 namespace {
 
-constexpr double kPlasma = 8.97866275;            // library.py:61
-constexpr double kGyro = 2.799249247e10;          // library.py:64
-constexpr double kBackoff = 1e-6;                 // library.py:378
+constexpr double kPlasma = 8.97866275;              // library.py:61
+constexpr double kGyro = 2.799249247e10;            // library.py:64
+constexpr double kBackoff = 1e-6;                   // library.py:378
 constexpr double kDegToRad = 0.017453292519943295;  // numpy deg2rad multiplies by pi/180
-constexpr double kUnmagTol = 1e-12;               // library.py:163
+constexpr double kUnmagTol = 1e-12;                 // library.py:163
+constexpr double kSmallAngle = 2e-3;                // rad per segment: Taylor rotation is exact to < 1e-19
 
+// One bottomside level.  u0..u2 depend on the tier:
+//   faithful: u0 = psi [deg], u1 = d(psi)/dz [deg/km], u2 unused
+//   fast:     u0 = sin(psi), u1 = cos(psi), u2 = d(psi)/dz [rad/km]
 struct __attribute__((aligned(16))) Node {
-    double alt, den, sden, b, sb, psi, spsi, pf2;
+    double alt, den, sden, b, sb, u0, u1, u2;
 };
 static_assert(sizeof(Node) == 64, "node must be 64 bytes");
 
@@ -53,13 +62,36 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------
+// fast-tier primitives: hardware estimate + Newton refinement to ~1 ulp, no range fix-ups
+// (arguments here are O(1e-20 .. 1e3), far from the subnormal range).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_refined(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// 1/sqrt(x); NaN for x < 0, +inf for x == 0.
+__device__ __forceinline__ double rsqrt_refined(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * y;
+    double e = __builtin_fma(-(x * y), h, 0.5);     // 0.5 - x*y*y/2
+    y = __builtin_fma(y, e, y);
+    h = 0.5 * y;
+    e = __builtin_fma(-(x * y), h, 0.5);
+    return __builtin_fma(y, e, y);
+}
+
+// ---------------------------------------------------------------------------------------
 // Appleton-Hartree group index, reference operation order (library.py:194-256).
-// SIGN = +1 ordinary, -1 extraordinary (library.py:221-224).
 // ---------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ double group_index_faithful(double X, double Y, double psi_deg) {
+__device__ __forceinline__ void index_faithful(double X, double Y, double psi_deg, double* mu_out,
+                                               double* mup_out) {
 #pragma clang fp contract(off)
-    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
+    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;   // library.py:221-224
     const double r = psi_deg * kDegToRad;
     double s, c;
     sincos(r, &s, &c);
@@ -86,24 +118,65 @@ __device__ __forceinline__ double group_index_faithful(double X, double Y, doubl
     const double two_mu = 2.0 * mu;
     const double dmudY = (XXm1 * dDdY) / (two_mu * (D * D));   // :250
     const double dmudX = (1.0 / (two_mu * D)) * (((2.0 * X) - 1.0) + q * dDdX);   // :251
-    return mu - ((2.0 * X) * dmudX + Y * dmudY);               // :254
+    *mu_out = mu;
+    *mup_out = mu - ((2.0 * X) * dmudX + Y * dmudY);           // :254
+}
+
+// Same quantities with shared reciprocals; s, c = sin/cos of the field angle.
+template <int MODE>
+__device__ __forceinline__ void index_fast(double X, double Y, double s, double c, double* mu_out,
+                                           double* mup_out) {
+#pragma clang fp contract(fast)
+    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
+    const double YT = Y * s;
+    const double YL = Y * c;
+    const double Xm1 = 1.0 - X;
+    const double YT2 = YT * YT;
+    const double YL2 = YL * YL;
+    const double Xm12 = Xm1 * Xm1;
+    const double h = 0.5 * YT2;
+    const double alpha = h * h + YL2 * Xm12;                   // :217
+    const double rbeta = rsqrt_refined(alpha);
+    const double beta = alpha * rbeta;                         // :218
+    const double D = (Xm1 - h) + sgn * beta;                   // :229
+    const double rD = rcp_refined(D);
+    const double q = (X * Xm1) * rD;
+    const double rad = 1.0 - q;                                // :232 (rad < 0 -> NaN through rsq)
+    const double rmu = rsqrt_refined(rad);
+    double mu = rad * rmu;
+    if (mu > 1.0) mu = qnan();                                 // :238
+    const double dbdX = -(YL2 * Xm1) * rbeta;                  // :241
+    const double dDdX = sgn * dbdX - 1.0;                      // :242
+    const double dadY = (YT2 * YT) * s + ((2.0 * YL) * Xm12) * c;   // :244-245
+    const double dbdY = (0.5 * dadY) * rbeta;                  // :246
+    const double dDdY = sgn * dbdY - YT * s;                   // :247
+    const double A = (0.5 * rmu) * rD;                         // 1 / (2 mu D)
+    const double two_X = 2.0 * X;
+    // :250-254 with dmu/dX = A (2X - 1 + q dD/dX), dmu/dY = A q dD/dY
+    const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + Y * (q * dDdY);
+    *mu_out = mu;
+    *mup_out = (mu == mu) ? mu - A * bracket : qnan();
 }
 
 // Isotropic plasma (library.py:201-207): mu = sqrt(1-X) for X < 1, mu' = 1/mu.
-__device__ __forceinline__ double group_index_unmagnetised(double X) {
+__device__ __forceinline__ void index_unmagnetised(double X, double* mu_out, double* mup_out) {
+#pragma clang fp contract(off)
     const double m2 = 1.0 - X;
-    if (!(m2 > 0.0)) return qnan();
+    if (!(m2 > 0.0)) { *mu_out = qnan(); *mup_out = qnan(); return; }
     const double mu = sqrt(m2);
-    return 1.0 / mu;
+    *mu_out = mu;
+    *mup_out = 1.0 / mu;
 }
 
 // ---------------------------------------------------------------------------------------
 // S3-S6: reflection height of one pair.  Returns false when the frequency escapes.
 // np.interp(1.0, running_max, alt) semantics (library.py:388-407): j = last level whose
 // running maximum is <= 1; exact hit returns alt[j]; otherwise linear between j and j+1.
+// Always IEEE arithmetic: the comparisons with 1.0 decide NaN masks.
 // ---------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes, int K, double f_hz,
+__device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes,
+                                                  const double* __restrict__ pf2, int K, double f_hz,
                                                   double f2, int lane, double* h_out) {
 #pragma clang fp contract(off)
     double lmax = -__builtin_inf();
@@ -113,7 +186,7 @@ __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes
         const int k = base + lane;
         double col = -__builtin_inf();
         if (k < K) {
-            col = nodes[k].pf2 / f2;                                        // :136 on (F,K)
+            col = pf2[k] / f2;                                               // :136 on (F,K)
             if (MODE == PRHF_KMODE_X) col = col + (kGyro * nodes[k].b) / f_hz;   // :157, :389
         }
         const unsigned long long hit = __ballot(col > 1.0);
@@ -151,27 +224,31 @@ struct BlockInfo {
     int K;            // bottomside levels (index of the density peak)
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
+    int uniform;      // altitude grid is uniform below the peak
+    int small_angle;  // every segment turns the field angle by < kSmallAngle
     double alt_min;   // min over the whole altitude column (:507)
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
+    double inv_step;  // 1 / level spacing (uniform grids)
 };
 
 constexpr int kHintBuckets = PRHF_HINT_BUCKETS;
 
 // Stage one profile into LDS.  Every thread of the block calls this.
-template <int THREADS>
+template <int TIER, int THREADS>
 __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ den,
                                                    const double* __restrict__ bmag,
                                                    const double* __restrict__ bpsi,
                                                    const double* __restrict__ alt,
                                                    const double* __restrict__ freq, int n_freq,
-                                                   int n_alt, Node* nodes, unsigned short* hint,
-                                                   double* red) {
+                                                   int n_alt, Node* nodes, double* pf2,
+                                                   unsigned short* hint, double* red) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
+    static_assert(8 * W <= PRHF_RED_DOUBLES, "reduction scratch too small");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // red layout: [0,W) peak value, [W,2W) peak index (as double), [2W,3W) alt min,
-    //             [3W,4W) freq min, [4W,5W) |B| max, [5W,6W) negative-density flag
+    // red rows of W doubles: 0 peak value, 1 peak index, 2 alt min, 3 freq min,
+    //                        4 |B| max, 5 negative density, 6 max angle step, 7 non-uniform grid
     // ---- phase 1: first-occurrence argmax of density, min altitude, min frequency ---------
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
@@ -215,70 +292,160 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     info.alt_min = amin;
     info.bad = 0;
     info.unmag = 0;
+    info.uniform = 0;
+    info.small_angle = 0;
     info.a0 = 0.0;
     info.inv_w = 0.0;
+    info.inv_step = 0.0;
     const int K = info.K;
     if (K == 0) {
         info.bad = PRHF_STATUS_PEAK0;
         return info;
     }
-    // ---- phase 2: nodes (values, np.interp slopes, f_N^2), |B| max, negative density ------
-    double bmax = 0.0;
-    int neg = 0;
+    // ---- phase 2: nodes (values, np.interp slopes), f_N^2, |B| max, negative density --------
+    const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
+    double bmax = 0.0, turn = 0.0;
+    int neg = 0, ragged = 0;
     for (int k = tid; k < K; k += THREADS) {
         const double a = alt[k], d = den[k], b = bmag[k], p = bpsi[k];
         Node nd;
-        nd.alt = a; nd.den = d; nd.b = b; nd.psi = p;
+        nd.alt = a; nd.den = d; nd.b = b;
+        double spsi = 0.0;
         if (k + 1 < K) {
             const double da = alt[k + 1] - a;
             nd.sden = (den[k + 1] - d) / da;       // numpy arr_interp: (dy[i+1]-dy[i])/(dx[i+1]-dx[i])
             nd.sb = (bmag[k + 1] - b) / da;
-            nd.spsi = (bpsi[k + 1] - p) / da;
+            spsi = (bpsi[k + 1] - p) / da;
+            turn = fmax(turn, fabs(bpsi[k + 1] - p) * kDegToRad);
+            ragged |= (fabs(da - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
         } else {
-            nd.sden = 0.0; nd.sb = 0.0; nd.spsi = 0.0;
+            nd.sden = 0.0; nd.sb = 0.0;
         }
-        const double fn = sqrt(d) * kPlasma;       // :96
-        nd.pf2 = fn * fn;                          // :136 numerator
+        if (TIER == 0) {
+            nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0;
+        } else {
+            double sp, cp;
+            sincos(p * kDegToRad, &sp, &cp);
+            nd.u0 = sp; nd.u1 = cp; nd.u2 = spsi * kDegToRad;
+        }
         nodes[k] = nd;
+        const double fn = sqrt(d) * kPlasma;       // :96
+        pf2[k] = fn * fn;                          // :136 numerator
         bmax = fmax(bmax, fabs(b));
         neg |= (d < 0.0) ? 1 : 0;
     }
     bmax = wave_max(bmax);
+    turn = wave_max(turn);
     neg = __any(neg) ? 1 : 0;
+    ragged = __any(ragged) ? 1 : 0;
     if (lane == 0) {
         red[4 * W + wave] = bmax;
         red[5 * W + wave] = (double)neg;
+        red[6 * W + wave] = turn;
+        red[7 * W + wave] = (double)ragged;
     }
     __syncthreads();
     bmax = red[4 * W];
     neg = (int)red[5 * W];
+    turn = red[6 * W];
+    ragged = (int)red[7 * W];
 #pragma unroll
     for (int w = 1; w < W; ++w) {
         bmax = fmax(bmax, red[4 * W + w]);
         neg |= (int)red[5 * W + w];
+        turn = fmax(turn, red[6 * W + w]);
+        ragged |= (int)red[7 * W + w];
     }
     if (neg) info.bad = PRHF_STATUS_NEGDEN;        // library.py:93-94
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
     info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    // ---- phase 3: hint table: hint[b] = last level with alt <= a0 + b*w ---------------------
+    info.small_angle = (turn < kSmallAngle) ? 1 : 0;
+    // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
     const double a0 = nodes[0].alt;
     const double span = nodes[K - 1].alt - a0;
-    const double w = span / (double)kHintBuckets;
     info.a0 = a0;
+    info.uniform = (!ragged && K > 1 && step0 > 0.0) ? 1 : 0;
+    info.inv_step = info.uniform ? 1.0 / step0 : 0.0;
     info.inv_w = (span > 0.0) ? (double)kHintBuckets / span : 0.0;
-    for (int b = tid; b < kHintBuckets; b += THREADS) {
-        const double t = a0 + (double)b * w;
-        int lo = 0, hi = K - 1;                   // invariant: alt[lo] <= t (alt[0] = a0 <= t)
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (nodes[mid].alt <= t) lo = mid; else hi = mid - 1;
+    if (!info.uniform) {
+        // hint[b] = last level with alt <= a0 + b*w
+        const double w = span / (double)kHintBuckets;
+        for (int b = tid; b < kHintBuckets; b += THREADS) {
+            const double t = a0 + (double)b * w;
+            int lo = 0, hi = K - 1;               // invariant: alt[lo] <= t (alt[0] = a0 <= t)
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (nodes[mid].alt <= t) lo = mid; else hi = mid - 1;
+            }
+            hint[b] = (unsigned short)lo;
         }
-        hint[b] = (unsigned short)lo;
+        __syncthreads();
     }
-    __syncthreads();
     return info;
+}
+
+// Segment of np.interp for abscissa z: alt[j] <= z < alt[j+1], clamped to [0, K-1].
+__device__ __forceinline__ int locate(const Node* __restrict__ nodes, const unsigned short* __restrict__ hint,
+                                      const BlockInfo& info, double z) {
+    const int K = info.K;
+    int j;
+    if (info.uniform) {
+        j = (int)((z - info.a0) * info.inv_step);
+        j = j < 0 ? 0 : (j > K - 1 ? K - 1 : j);
+    } else {
+        int bucket = (int)((z - info.a0) * info.inv_w);
+        bucket = bucket < 0 ? 0 : (bucket > kHintBuckets - 1 ? kHintBuckets - 1 : bucket);
+        j = hint[bucket];
+    }
+    while (j > 0 && z < nodes[j].alt) --j;
+    while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+    return j;
+}
+
+// mu' at abscissa offset dz >= 0 inside the segment that starts at node nd.
+template <int MODE, int TIER, bool UNMAG>
+__device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_hz, double f2, double cX,
+                                            double cY, bool small_angle) {
+    double mu, mup;
+    if (TIER == 0) {
+#pragma clang fp contract(off)
+        const double den = nd.sden * dz + nd.den;      // numpy arr_interp: slope*(x - xp[j]) + fp[j]
+        const double fn = sqrt(den) * kPlasma;         // :96
+        const double X = (fn * fn) / f2;               // :136
+        if (UNMAG) {
+            index_unmagnetised(X, &mu, &mup);
+        } else {
+            const double b = nd.sb * dz + nd.b;
+            const double psi = nd.u1 * dz + nd.u0;
+            const double Y = (kGyro * b) / f_hz;       // :157
+            index_faithful<MODE>(X, Y, psi, &mu, &mup);
+        }
+    } else {
+#pragma clang fp contract(fast)
+        const double den = nd.sden * dz + nd.den;
+        const double X = den * cX;                     // cX = cp^2 / f^2
+        if (UNMAG) {
+            index_unmagnetised(X, &mu, &mup);
+        } else {
+            const double b = nd.sb * dz + nd.b;
+            const double Y = b * cY;                   // cY = g_p / f
+            const double d = nd.u2 * dz;               // angle turned since the node [rad]
+            double sd, cd;
+            if (small_angle) {
+                const double d2 = d * d;
+                sd = d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0)));
+                cd = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0));
+            } else {
+                sincos(d, &sd, &cd);
+            }
+            const double s = nd.u0 * cd + nd.u1 * sd;
+            const double c = nd.u1 * cd - nd.u0 * sd;
+            index_fast<MODE>(X, Y, s, c, &mu, &mup);
+        }
+    }
+    return mup;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,37 +457,30 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                                                   const BlockInfo& info, const double* __restrict__ mult,
                                                   int n_points, int i0, int i1, double f_hz, double f2,
                                                   double h_refl, int lane) {
-#pragma clang fp contract(off)
-    const int K = info.K;
     const double a0 = info.a0;
     const double span = h_refl - a0;               // :413 (critical_height - aalt[0])
+    const double cX = (kPlasma * kPlasma) / f2;
+    const double cY = kGyro / f_hz;
+    const bool small_angle = info.small_angle != 0;
     double acc = 0.0;
     for (int i = i0 + lane; i < i1; i += 64) {
-        const double z = mult[i] * span + a0;      // :413
-        double dh = kBackoff;                      // :415-416 last thickness
-        if (i + 1 < n_points) dh = (mult[i + 1] * span + a0) - z;
-        // segment of np.interp: alt[j] <= z < alt[j+1]
-        int bucket = (int)((z - a0) * info.inv_w);
-        bucket = bucket < 0 ? 0 : (bucket > kHintBuckets - 1 ? kHintBuckets - 1 : bucket);
-        int j = hint[bucket];
-        while (j > 0 && z < nodes[j].alt) --j;
-        while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+        double z, dh;
+        if (TIER == 0) {
+#pragma clang fp contract(off)
+            z = mult[i] * span + a0;               // :413
+            dh = kBackoff;                         // :415-416 last thickness
+            if (i + 1 < n_points) dh = (mult[i + 1] * span + a0) - z;
+        } else {
+            const double m0 = mult[i];
+            z = __builtin_fma(m0, span, a0);
+            dh = kBackoff;
+            if (i + 1 < n_points) dh = (mult[i + 1] - m0) * span;
+        }
+        const int j = locate(nodes, hint, info, z);
         const Node nd = nodes[j];
         double dz = z - nd.alt;
         if (dz < 0.0) dz = 0.0;                    // z below the first level: left value
-        const double den = nd.sden * dz + nd.den;  // numpy arr_interp: slope*(x - xp[j]) + fp[j]
-        double mup;
-        if (UNMAG) {
-            const double fn = sqrt(den) * kPlasma;
-            mup = group_index_unmagnetised((fn * fn) / f2);
-        } else {
-            const double b = nd.sb * dz + nd.b;
-            const double psi = nd.spsi * dz + nd.psi;
-            const double fn = sqrt(den) * kPlasma;     // :96
-            const double X = (fn * fn) / f2;           // :136
-            const double Y = (kGyro * b) / f_hz;       // :157
-            mup = group_index_faithful<MODE>(X, Y, psi);
-        }
+        const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY, small_angle);
         const double term = mup * dh;              // :288
         if (term == term) acc = acc + term;        // nansum
     }
@@ -329,8 +489,8 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
 
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
-                                          const unsigned short* hint, const BlockInfo& info,
-                                          long long prof_local, int block_in_prof) {
+                                          const double* pf2, const unsigned short* hint,
+                                          const BlockInfo& info, long long prof_local, int block_in_prof) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int F = (int)a.n_freq;
@@ -347,7 +507,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
             const double f_hz = a.freq[f] * 1e6;               // :491
             const double f2 = f_hz * f_hz;                     // f**2
             double h;
-            reflects = reflection_height<MODE>(nodes, info.K, f_hz, f2, lane, &h);
+            reflects = reflection_height<MODE>(nodes, pf2, info.K, f_hz, f2, lane, &h);
             if (reflects) {
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
@@ -357,6 +517,21 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 else
                     result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, sg.n_points, i0, i1,
                                                                 f_hz, f2, h, lane);
+            } else if (info.K == 1) {
+                // A one-level bottomside: np.interp with a single node returns that node even
+                // for the NaN abscissae of an escaping frequency (numpy arr_interp, lenxp == 1),
+                // so the reference's sum keeps the last term mu'(level 0) * 1e-6 (:415-416, :288).
+                const double cX = (kPlasma * kPlasma) / f2, cY = kGyro / f_hz;
+                double term = 0.0;
+                if (c == C - 1) {
+                    const double mup = info.unmag
+                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY, true)
+                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY, true);
+                    term = mup * kBackoff;
+                    if (!(term == term)) term = 0.0;
+                }
+                result = term;
+                reflects = true;
             }
         }
         if (lane == 0) {
@@ -378,8 +553,9 @@ __global__ __launch_bounds__(THREADS) void vfo_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_alt = (int)a.n_alt;
     Node* nodes = reinterpret_cast<Node*>(smem);
-    unsigned short* hint = reinterpret_cast<unsigned short*>(smem + (size_t)n_alt * sizeof(Node));
-    double* red = reinterpret_cast<double*>(smem + (size_t)n_alt * sizeof(Node) +
+    double* pf2 = reinterpret_cast<double*>(smem + (size_t)n_alt * sizeof(Node));
+    unsigned short* hint = reinterpret_cast<unsigned short*>(pf2 + n_alt);
+    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
                                             kHintBuckets * sizeof(unsigned short));
 
     const long long bid = blockIdx.x;
@@ -391,17 +567,17 @@ __global__ __launch_bounds__(THREADS) void vfo_kernel(const KArgs a) {
     const int block_in_prof = (int)(lb % sg.blocks_per_prof);
     const long long p = sg.prof_begin + prof_local;
 
-    const BlockInfo info = stage_profile<THREADS>(a.den + p * a.prof_stride, a.bmag + p * a.prof_stride,
-                                                  a.bpsi + p * a.prof_stride, a.alt + p * a.alt_stride,
-                                                  a.freq, (int)a.n_freq, n_alt, nodes, hint, red);
+    const BlockInfo info = stage_profile<TIER, THREADS>(
+        a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
+        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, n_alt, nodes, pf2, hint, red);
     if (threadIdx.x == 0 && block_in_prof == 0) {
         if (info.bad) atomicOr(a.status, (unsigned)info.bad);
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
     }
     if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, hint, info, prof_local, block_in_prof);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, hint, info, prof_local, block_in_prof);
 }
 
 // Chunked pairs: add the chunk sums in a fixed order, then the reference's 0 -> NaN and + min(alt).
@@ -417,6 +593,51 @@ __global__ void vfo_finalize_kernel(const KArgs a, int s) {
     a.out[sg.out_off + t] = (sum == sum && sum != 0.0) ? sum + amin : qnan();
 }
 
+// Standalone Appleton-Hartree indices on flat arrays (find_mu_mup, library.py:161-256).
+// `unmag` is decided by the caller over the whole array, as the reference does (:201).
+template <int TIER>
+__global__ void mu_mup_kernel(const double* __restrict__ X, const double* __restrict__ Y,
+                              const double* __restrict__ psi, long long n, int mode, int unmag,
+                              double* __restrict__ mu_out, double* __restrict__ mup_out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double mu, mup;
+        if (unmag) {
+            index_unmagnetised(X[i], &mu, &mup);
+        } else if (TIER == 0) {
+            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(X[i], Y[i], psi[i], &mu, &mup);
+            else index_faithful<PRHF_KMODE_X>(X[i], Y[i], psi[i], &mu, &mup);
+        } else {
+            double s, c;
+            sincos(psi[i] * kDegToRad, &s, &c);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], Y[i], s, c, &mu, &mup);
+            else index_fast<PRHF_KMODE_X>(X[i], Y[i], s, c, &mu, &mup);
+        }
+        mu_out[i] = mu;
+        mup_out[i] = mup;
+    }
+}
+
+// max |Y| ignoring NaN (np.nanmax(np.abs(Y)), library.py:201) in result[0] (bit pattern of a
+// non-negative double orders like the integer); result[1] != 0 when any element was not NaN.
+// Both words must start at 0.
+__global__ void absmax_kernel(const double* __restrict__ Y, long long n, unsigned long long* result) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    double m = 0.0;
+    int seen = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double y = fabs(Y[i]);
+        m = fmax(m, y);
+        seen |= (y == y) ? 1 : 0;
+    }
+    m = wave_max(m);
+    seen = __any(seen) ? 1 : 0;
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(result, (unsigned long long)__double_as_longlong(m));
+        if (seen) atomicOr(result + 1, 1ull);
+    }
+}
+
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;
     if (n_blocks <= 0) return hipSuccess;
@@ -429,12 +650,36 @@ hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_b
     for (int s = 0; s < a.n_segs; ++s) {
         if (a.seg[s].chunks <= 1) continue;
         const long long n_pairs = (a.seg[s].prof_end - a.seg[s].prof_begin) * a.n_freq;
+        if (n_pairs <= 0) continue;
         const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
         hipLaunchKernelGGL(vfo_finalize_kernel, dim3(blocks), dim3(256), 0, stream, a, s);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
+                         unsigned long long* absmax_scratch, unsigned long long* absmax_host,
+                         double* mu, double* mup, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipError_t e = hipMemsetAsync(absmax_scratch, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, Y, n, absmax_scratch);
+    e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    double ymax;
+    __builtin_memcpy(&ymax, absmax_host, sizeof ymax);
+    // all-NaN Y: np.nanmax gives NaN and the comparison is false -> magnetised formulas
+    const int unmag = (absmax_host[1] != 0 && ymax < kUnmagTol) ? 1 : 0;
+    if (tier == 0)
+        hipLaunchKernelGGL(mu_mup_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup);
+    else
+        hipLaunchKernelGGL(mu_mup_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup);
+    return hipGetLastError();
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes) {

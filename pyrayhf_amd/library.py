@@ -23,9 +23,12 @@ from . import _native, logger
 
 __all__ = [
     "constants", "den2freq", "freq2den", "find_X", "find_Y", "smooth_nonuniform_grid",
-    "vertical_to_magnetic_angle", "vertical_forward_operator", "vertical_forward_operator_mixed",
-    "last_kernel_ms",
+    "vertical_to_magnetic_angle", "find_mu_mup", "vertical_forward_operator",
+    "vertical_forward_operator_mixed", "last_kernel_ms", "MATH_FAITHFUL", "MATH_FAST",
 ]
+
+MATH_FAITHFUL = _native.MATH_FAITHFUL   # reference operation order, IEEE divide / sqrt
+MATH_FAST = _native.MATH_FAST           # shared reciprocals, rotation sin/cos, FMA contraction
 
 
 # ----------------------------------------------------------------------------------------
@@ -84,6 +87,37 @@ _MODE_CODE = {"O": _native.MODE_O, "X": _native.MODE_X}
 _mult_cache = {}
 
 
+def _default_math(mode_code, math):
+    """O mode is ill conditioned near reflection and keeps the reference's operation order;
+    X mode (conditioning ~1e-11) takes the fast tier.  DESIGN.md "Arithmetic tiers"."""
+    if math is not None:
+        return int(math)
+    return MATH_FAITHFUL if mode_code == _native.MODE_O else MATH_FAST
+
+
+def find_mu_mup(X, Y, bpsi, mode, *, device=None, math=None):
+    """Appleton-Hartree phase and group refractive indices on the GPU.
+
+    Same arguments and results as the reference's ``find_mu_mup`` (library.py:161-256): ``X``,
+    ``Y``, ``bpsi`` (degrees) broadcastable arrays, ``mode`` 'O' or 'X'; returns ``(mu, mup)``
+    with the inputs' broadcast shape.  The isotropic formulas are used when ``nanmax|Y| <
+    1e-12`` over the whole array, as in the reference.  Default tier: faithful.
+    """
+    if mode not in _MODE_CODE:
+        raise ValueError("Mode must be O or X")                   # reference library.py:225-226
+    X, Y, bpsi = np.broadcast_arrays(np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64),
+                                     np.asarray(bpsi, dtype=np.float64))
+    shape = X.shape
+    x, y, p = (np.ascontiguousarray(a).reshape(-1) for a in (X, Y, bpsi))
+    mu = np.empty(x.size, dtype=np.float64)
+    mup = np.empty(x.size, dtype=np.float64)
+    ctx = _native.context(device)
+    ctx.set_math(MATH_FAITHFUL if math is None else int(math))
+    _native.raise_for(ctx.mu_mup(x.ctypes.data, y.ctypes.data, p.ctypes.data, x.size, _MODE_CODE[mode],
+                                 mu.ctypes.data, mup.ctypes.data, 0))
+    return mu.reshape(shape), mup.reshape(shape)
+
+
 def _mode_code(mode):
     try:
         return _MODE_CODE[mode]
@@ -134,8 +168,7 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     mult = _multiplier(n_points)
     out = np.empty((n_prof, f.size), dtype=np.float64)
     ctx = _native.context(device)
-    if math is not None:
-        ctx.set_math(math)
+    ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                        n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
                        out.ctypes.data, 0)
@@ -177,8 +210,7 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
         raise ValueError("out must be a contiguous float64 tensor of shape (P, F)")
     ctx = _native.context(dev.index if dev.index is not None else torch.cuda.current_device())
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    if math is not None:
-        ctx.set_math(math)
+    ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
                        n_prof, n_alt, n_alt, alt_stride, mult.data_ptr(), int(n_points), mode_code,
                        out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC)
@@ -202,7 +234,8 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     frequency is not reflected below the density peak.
 
     Keyword-only extensions: ``device`` (GPU index for host inputs; default ``PRHF_DEVICE``
-    / ``LOCAL_RANK`` / 0), ``math`` (``pyrayhf_amd.MATH_FAITHFUL`` / ``MATH_FAST``),
+    / ``LOCAL_RANK`` / 0), ``math`` (``MATH_FAITHFUL`` / ``MATH_FAST``; default faithful for
+    'O', fast for 'X'),
     and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
 
     Raises ``ValueError("mode must be 'O' or 'X'")``, ``ValueError("Density must be
@@ -242,8 +275,9 @@ def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, dev
     if not segs:
         return out
     ctx = _native.context(device)
-    if math is not None:
-        ctx.set_math(math)
+    # one tier per launch: faithful unless every slice is X mode (or the caller chooses)
+    all_x = all(sg.mode == _native.MODE_X for sg in segs)
+    ctx.set_math(_default_math(_native.MODE_X if all_x else _native.MODE_O, math))
     # the library writes only the rows its segments cover: stage `out` through the call
     rc = ctx.vfo_worklist(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                           n_prof, n_alt, n_alt, n_alt if a.ndim == 2 else 0, mult.ctypes.data, mult.size,

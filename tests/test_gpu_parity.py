@@ -72,9 +72,53 @@ def test_chapman_batch_g5(lib):
     assert_o_mode(vo, g["O_200_vh"], g["O_200_noise"])
     vx = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000)
     assert_x_mode(vx, g["X_2000_vh"])
-    # batch == loop of single-profile calls, bit for bit
+    # batch == loop of single-profile calls (a lone profile is cut into more chunks, so the
+    # summation order differs: agreement to rounding, not bit for bit)
     one = lib.vertical_forward_operator(g["freq"], g["den"][5], g["bmag"][5], g["bpsi"][5], g["alt"], "X", 2000)
-    assert np.array_equal(one, vx[5], equal_nan=True)
+    assert_x_mode(one, vx[5], tol=1e-12)
+
+
+@pytest.mark.parametrize("math", ["faithful", "fast"])
+def test_both_tiers_both_modes(lib, math):
+    """Every (tier, mode) combination against the reference vectors, not just the defaults."""
+    g = load_golden("g5_chapman64.npz")
+    level = lib.MATH_FAITHFUL if math == "faithful" else lib.MATH_FAST
+    vx = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000, math=level)
+    print(math, "X max rel err", assert_x_mode(vx, g["X_2000_vh"]))
+    vo = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 200, math=level)
+    err, ok = rel_err(vo, g["O_200_vh"])
+    print(math, "O max rel err", err.max(), "within 1e-6:", (err[ok] <= 1e-6).mean())
+    assert_o_mode(vo, g["O_200_vh"], g["O_200_noise"], factor=4.0 if math == "faithful" else 16.0)
+
+
+@pytest.mark.parametrize("math", ["faithful", "fast"])
+def test_find_mu_mup_device_op(lib, math):
+    level = lib.MATH_FAITHFUL if math == "faithful" else lib.MATH_FAST
+    g = load_golden("g3_index_kat.npz")
+    mu, mup = lib.find_mu_mup(g["X"], g["Y"], g["psi"], "O", math=level)
+    np.testing.assert_allclose(mu, g["mu_published"], rtol=1e-5)       # reference test_core.py:137-152
+    np.testing.assert_allclose(mup, g["mup_published"], rtol=1e-5)
+    np.testing.assert_allclose(mu, g["mu_O"], rtol=1e-12)
+    np.testing.assert_allclose(mup, g["mup_O"], rtol=1e-10)
+    mu, mup = lib.find_mu_mup(g["X"], g["Y"], g["psi"], "X", math=level)
+    assert np.array_equal(np.isnan(mu), np.isnan(g["mu_X"])) and np.array_equal(np.isnan(mup), np.isnan(g["mup_X"]))
+    ok = np.isfinite(g["mu_X"])
+    np.testing.assert_allclose(mu[ok], g["mu_X"][ok], rtol=1e-12)
+    np.testing.assert_allclose(mup[ok], g["mup_X"][ok], rtol=1e-10)
+    mu, mup = lib.find_mu_mup(g["unmag_X"], np.zeros(3), g["psi"], "O", math=level)    # isotropic branch
+    assert np.array_equal(np.isnan(mu), np.isnan(g["unmag_mu"]))
+    np.testing.assert_allclose(mu[:1], g["unmag_mu"][:1], rtol=1e-15)
+    np.testing.assert_allclose(mup[:1], g["unmag_mup"][:1], rtol=1e-15)
+    with pytest.raises(ValueError, match="Mode must be O or X"):
+        lib.find_mu_mup(g["X"], g["Y"], g["psi"], "Z")
+    # 2-D stage captures of the Day profile (fixture G6): X-mode is well conditioned everywhere
+    s = load_golden("g6_stages.npz")
+    mu, mup = lib.find_mu_mup(s["X_X"], s["X_Y"], s["X_bpsi"], "X", math=level)
+    assert mu.shape == s["X_mu"].shape
+    ok = np.isfinite(s["X_mup"])
+    assert np.array_equal(np.isnan(mup), ~ok)
+    np.testing.assert_allclose(mu[ok], s["X_mu"][ok], rtol=1e-9)
+    np.testing.assert_allclose(mup[ok], s["X_mup"][ok], rtol=1e-7)
 
 
 def test_edge_cases_g7(lib):
