@@ -37,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr long long kTargetWaves = 8192;   // ~1.3x the waves resident at 3 blocks per CU
-constexpr long long kMaxAlt = 2200;        // nodes + hints must fit 160 KiB of LDS
+constexpr long long kMaxAlt = 1600;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
 struct DevBuf {

@@ -15,7 +15,9 @@
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
 #define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
-#define PRHF_RED_DOUBLES 64         // block-reduction scratch (6 * waves, rounded up)
+#define PRHF_RED_DOUBLES 64         // block-reduction scratch (8 rows x waves)
+#define PRHF_NODE_BYTES 80          // one staged bottomside level
+#define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
 
 namespace prhf {
 
@@ -50,9 +52,11 @@ struct KArgs {
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 
-// nodes (64 B) + f_N^2 (8 B) per level, segment hints, block-reduction scratch
+// n_alt + 1 nodes (the last one may be the +inf sentinel), f_N^2 and g_p*B per level,
+// segment hints, block-reduction scratch
 inline size_t lds_bytes_for(long long n_alt) {
-    return (size_t)n_alt * 72 + PRHF_HINT_BUCKETS * 2 + PRHF_RED_DOUBLES * 8;
+    return (size_t)(n_alt + 1) * PRHF_NODE_BYTES + (size_t)n_alt * 16 + PRHF_HINT_BUCKETS * 2 +
+           PRHF_RED_DOUBLES * 8;
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes);

@@ -2,8 +2,8 @@
 //
 // One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its
 // stretched grid when few pairs are submitted.  A workgroup shares one profile: its
-// bottomside columns are staged once into LDS as 64-byte nodes, so that every grid point
-// costs four ds_read_b128 and no HBM traffic.  Per pair:
+// bottomside columns are staged once into LDS as 80-byte nodes, so that every grid point
+// costs five ds_read_b128 and no HBM traffic.  Per pair:
 //   S3-S6  reflection height: lanes stride over the levels, first level with X (or X+Y) > 1
 //          by ballot, running maximum below it by a wave max-reduce, np.interp semantics;
 //   S7-S10 lanes stride over the n_points stretched altitudes: locate the segment (closed
@@ -14,8 +14,8 @@
 //
 // Two arithmetic tiers (DESIGN.md "Arithmetic tiers"):
 //   TIER 0 "faithful": the reference's operation order, IEEE divide and sqrt, no contraction;
-//   TIER 1 "fast":     shared reciprocals / rsqrt with Newton refinement, sin/cos of the
-//                      interpolated angle by rotation from node values, FMA contraction.
+//   TIER 1 "fast":     algebraically reduced mu' (57 FP64 operations + 2 v_rsq_f64 per point),
+//                      sin^2(psi) by a per-segment cubic, FMA contraction.
 //
 // No MFMA: the work is elementwise float64 transcendental + reduction ("Roofline").
 
@@ -33,15 +33,16 @@ constexpr double kGyro = 2.799249247e10;            // library.py:64
 constexpr double kBackoff = 1e-6;                   // library.py:378
 constexpr double kDegToRad = 0.017453292519943295;  // numpy deg2rad multiplies by pi/180
 constexpr double kUnmagTol = 1e-12;                 // library.py:163
-constexpr double kSmallAngle = 2e-3;                // rad per segment: Taylor rotation is exact to < 1e-19
+constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
 
-// One bottomside level.  u0..u2 depend on the tier:
-//   faithful: u0 = psi [deg], u1 = d(psi)/dz [deg/km], u2 unused
-//   fast:     u0 = sin(psi), u1 = cos(psi), u2 = d(psi)/dz [rad/km]
+// One bottomside level.  u0..u3 depend on the tier and (fast tier) on the profile:
+//   faithful:            u0 = psi [deg], u1 = d(psi)/dz [deg/km]
+//   fast, small turning: sin^2(psi(z)) = u0 + dz*(u1 + dz*(u2 + dz*u3)) inside the segment
+//   fast, large turning: u0 = psi [rad], u1 = d(psi)/dz [rad/km]
 struct __attribute__((aligned(16))) Node {
-    double alt, den, sden, b, sb, u0, u1, u2;
+    double alt, den, sden, b, sb, u0, u1, u2, u3, pad;
 };
-static_assert(sizeof(Node) == 64, "node must be 64 bytes");
+static_assert(sizeof(Node) == PRHF_NODE_BYTES, "node size");
 
 __device__ __forceinline__ double qnan() { return __builtin_nan(""); }
 
@@ -61,27 +62,24 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------
-// fast-tier primitives: hardware estimate + Newton refinement to ~1 ulp, no range fix-ups
-// (arguments here are O(1e-20 .. 1e3), far from the subnormal range).
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double rcp_refined(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, e, y);
+// Wave-uniform values computed by the vector ALU live in VGPRs unless told otherwise; moving
+// them to SGPRs keeps the hot loop under the 128-VGPR budget of two workgroups per CU.
+__device__ __forceinline__ double uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// 1/sqrt(x); NaN for x < 0, +inf for x == 0.
-__device__ __forceinline__ double rsqrt_refined(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * y;
-    double e = __builtin_fma(-(x * y), h, 0.5);     // 0.5 - x*y*y/2
-    y = __builtin_fma(y, e, y);
-    h = 0.5 * y;
-    e = __builtin_fma(-(x * y), h, 0.5);
-    return __builtin_fma(y, e, y);
+// 1/sqrt(x) to ~0.6 ulp: v_rsq_f64 is good to 2^-24 on gfx950 (tools/probe_math.hip), one
+// third-order step cubes that.  NaN for x < 0, +inf for x == 0; no range fix-ups (arguments
+// here are O(1e-30 .. 1e3), far from the subnormal range).
+__device__ __forceinline__ double rsqrt_cubic(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double t = x * y;
+    const double e = __builtin_fma(-t, y, 1.0);            // 1 - x y^2
+    const double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, p, y);                     // y (1 + e/2 + 3 e^2/8)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -122,40 +120,44 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     *mup_out = mu - ((2.0 * X) * dmudX + Y * dmudY);           // :254
 }
 
-// Same quantities with shared reciprocals; s, c = sin/cos of the field angle.
+// The same mu and mu' in reduced form.  With S2 = sin^2 psi, C2 = cos^2 psi, Y2 = Y^2:
+//   h = YT^2/2, alpha = h^2 + YL^2 (1-X)^2, beta = sqrt(alpha), D = (1-X) - h +- beta   (:217-229)
+//   mu^2 = N/D with N = D - X(1-X)                                                    (:232)
+//   1/(2 mu D) = sign(D) / (2 sqrt(N D))  -> one rsqrt gives mu, 1/D and that factor
+//   Y dD/dY = -2h +- (beta + h^2/beta)      (from :244-247, using Y d(alpha)/dY = 4h^2 + 2 YL^2 (1-X)^2)
+//   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
 template <int MODE>
-__device__ __forceinline__ void index_fast(double X, double Y, double s, double c, double* mu_out,
+__device__ __forceinline__ void index_fast(double X, double Y2, double S2, double C2, double* mu_out,
                                            double* mup_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
-    const double YT = Y * s;
-    const double YL = Y * c;
     const double Xm1 = 1.0 - X;
-    const double YT2 = YT * YT;
-    const double YL2 = YL * YL;
     const double Xm12 = Xm1 * Xm1;
-    const double h = 0.5 * YT2;
-    const double alpha = h * h + YL2 * Xm12;                   // :217
-    const double rbeta = rsqrt_refined(alpha);
-    const double beta = alpha * rbeta;                         // :218
-    const double D = (Xm1 - h) + sgn * beta;                   // :229
-    const double rD = rcp_refined(D);
-    const double q = (X * Xm1) * rD;
-    const double rad = 1.0 - q;                                // :232 (rad < 0 -> NaN through rsq)
-    const double rmu = rsqrt_refined(rad);
-    double mu = rad * rmu;
-    if (mu > 1.0) mu = qnan();                                 // :238
-    const double dbdX = -(YL2 * Xm1) * rbeta;                  // :241
-    const double dDdX = sgn * dbdX - 1.0;                      // :242
-    const double dadY = (YT2 * YT) * s + ((2.0 * YL) * Xm12) * c;   // :244-245
-    const double dbdY = (0.5 * dadY) * rbeta;                  // :246
-    const double dDdY = sgn * dbdY - YT * s;                   // :247
-    const double A = (0.5 * rmu) * rD;                         // 1 / (2 mu D)
-    const double two_X = 2.0 * X;
-    // :250-254 with dmu/dX = A (2X - 1 + q dD/dX), dmu/dY = A q dD/dY
-    const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + Y * (q * dDdY);
+    const double YL2 = Y2 * C2;
+    const double h = 0.5 * (Y2 * S2);
+    const double h2 = h * h;
+    const double alpha = h2 + YL2 * Xm12;
+    const double rbeta = rsqrt_cubic(alpha);
+    const double beta = alpha * rbeta;
+    const double D = (Xm1 - h) + sgn * beta;
+    const double XXm1 = X * Xm1;
+    const double N = D - XXm1;
+    const double w = rsqrt_cubic(N * D);                       // NaN when mu^2 < 0 (:233)
+    const double Nw = N * w;
+    double mu = __builtin_fabs(Nw);
+    const double rD = Nw * w;
+    const double q = XXm1 * rD;
+    const double dDdX = -sgn * ((YL2 * Xm1) * rbeta) - 1.0;    // :241-242
+    const double YdDdY = sgn * (h2 * rbeta + beta) - 2.0 * h;
+    const double two_X = X + X;
+    const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + q * YdDdY;
+    const double A = __builtin_copysign(0.5 * w, D);
+    double mup = mu - A * bracket;
+    // :238 mu > 1 -> NaN.  In vacuum (X -> 0) mu is 1 to rounding, so the cliff must sit where
+    // the reference's does: sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) > 1 + 2^-52.
+    if (1.0 - q > 1.0000000000000002) { mu = qnan(); mup = qnan(); }
     *mu_out = mu;
-    *mup_out = (mu == mu) ? mu - A * bracket : qnan();
+    *mup_out = mup;
 }
 
 // Isotropic plasma (library.py:201-207): mu = sqrt(1-X) for X < 1, mu' = 1/mu.
@@ -176,7 +178,8 @@ __device__ __forceinline__ void index_unmagnetised(double X, double* mu_out, dou
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes,
-                                                  const double* __restrict__ pf2, int K, double f_hz,
+                                                  const double* __restrict__ pf2,
+                                                  const double* __restrict__ gb, int K, double f_hz,
                                                   double f2, int lane, double* h_out) {
 #pragma clang fp contract(off)
     double lmax = -__builtin_inf();
@@ -186,8 +189,8 @@ __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes
         const int k = base + lane;
         double col = -__builtin_inf();
         if (k < K) {
-            col = pf2[k] / f2;                                               // :136 on (F,K)
-            if (MODE == PRHF_KMODE_X) col = col + (kGyro * nodes[k].b) / f_hz;   // :157, :389
+            col = pf2[k] / f2;                                          // :136 on (F,K)
+            if (MODE == PRHF_KMODE_X) col = col + gb[k] / f_hz;         // :157, :389
         }
         const unsigned long long hit = __ballot(col > 1.0);
         if (hit) {
@@ -225,7 +228,7 @@ struct BlockInfo {
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
-    int small_angle;  // every segment turns the field angle by < kSmallAngle
+    int poly_angle;   // fast tier: sin^2(psi) cubic per segment is valid
     double alt_min;   // min over the whole altitude column (:507)
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
@@ -241,7 +244,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                                                    const double* __restrict__ bpsi,
                                                    const double* __restrict__ alt,
                                                    const double* __restrict__ freq, int n_freq,
-                                                   int n_alt, Node* nodes, double* pf2,
+                                                   int n_alt, Node* nodes, double* pf2, double* gb,
                                                    unsigned short* hint, double* red) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
@@ -288,12 +291,13 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         fm = fmin(fm, red[3 * W + w]);
     }
     BlockInfo info;
-    info.K = (bi == 0x7fffffff) ? 0 : bi;      // library.py:371-375: levels [0, argmax)
-    info.alt_min = amin;
+    info.K = uniform((bi == 0x7fffffff) ? 0 : bi);      // library.py:371-375: levels [0, argmax)
+    info.alt_min = uniform(amin);
+    fm = uniform(fm);
     info.bad = 0;
     info.unmag = 0;
     info.uniform = 0;
-    info.small_angle = 0;
+    info.poly_angle = 0;
     info.a0 = 0.0;
     info.inv_w = 0.0;
     info.inv_step = 0.0;
@@ -302,37 +306,17 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         info.bad = PRHF_STATUS_PEAK0;
         return info;
     }
-    // ---- phase 2: nodes (values, np.interp slopes), f_N^2, |B| max, negative density --------
+    // ---- phase 2a: per-profile flags that decide the node contents -------------------------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
     double bmax = 0.0, turn = 0.0;
     int neg = 0, ragged = 0;
     for (int k = tid; k < K; k += THREADS) {
-        const double a = alt[k], d = den[k], b = bmag[k], p = bpsi[k];
-        Node nd;
-        nd.alt = a; nd.den = d; nd.b = b;
-        double spsi = 0.0;
+        bmax = fmax(bmax, fabs(bmag[k]));
+        neg |= (den[k] < 0.0) ? 1 : 0;
         if (k + 1 < K) {
-            const double da = alt[k + 1] - a;
-            nd.sden = (den[k + 1] - d) / da;       // numpy arr_interp: (dy[i+1]-dy[i])/(dx[i+1]-dx[i])
-            nd.sb = (bmag[k + 1] - b) / da;
-            spsi = (bpsi[k + 1] - p) / da;
-            turn = fmax(turn, fabs(bpsi[k + 1] - p) * kDegToRad);
-            ragged |= (fabs(da - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
-        } else {
-            nd.sden = 0.0; nd.sb = 0.0;
+            turn = fmax(turn, fabs(bpsi[k + 1] - bpsi[k]) * kDegToRad);
+            ragged |= (fabs((alt[k + 1] - alt[k]) - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
         }
-        if (TIER == 0) {
-            nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0;
-        } else {
-            double sp, cp;
-            sincos(p * kDegToRad, &sp, &cp);
-            nd.u0 = sp; nd.u1 = cp; nd.u2 = spsi * kDegToRad;
-        }
-        nodes[k] = nd;
-        const double fn = sqrt(d) * kPlasma;       // :96
-        pf2[k] = fn * fn;                          // :136 numerator
-        bmax = fmax(bmax, fabs(b));
-        neg |= (d < 0.0) ? 1 : 0;
     }
     bmax = wave_max(bmax);
     turn = wave_max(turn);
@@ -356,15 +340,60 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         turn = fmax(turn, red[6 * W + w]);
         ragged |= (int)red[7 * W + w];
     }
+    bmax = uniform(bmax);
+    turn = uniform(turn);
+    neg = uniform(neg);
+    ragged = uniform(ragged);
     if (neg) info.bad = PRHF_STATUS_NEGDEN;        // library.py:93-94
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
     info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    info.small_angle = (turn < kSmallAngle) ? 1 : 0;
+    info.poly_angle = (turn < kPolyAngle) ? 1 : 0;
+    // ---- phase 2b: nodes (values, np.interp slopes), f_N^2, g_p B -----------------------------
+    for (int k = tid; k <= K; k += THREADS) {
+        Node nd;
+        if (k == K) {                              // sentinel: no abscissa is >= +inf
+            nd.alt = __builtin_inf();
+            nd.den = nd.sden = nd.b = nd.sb = nd.u0 = nd.u1 = nd.u2 = nd.u3 = nd.pad = 0.0;
+            nodes[k] = nd;
+            continue;
+        }
+        const double a = alt[k], d = den[k], b = bmag[k], p = bpsi[k];
+        nd.alt = a; nd.den = d; nd.b = b; nd.pad = 0.0;
+        double spsi = 0.0;
+        if (k + 1 < K) {
+            const double da = alt[k + 1] - a;
+            nd.sden = (den[k + 1] - d) / da;       // numpy arr_interp: (dy[i+1]-dy[i])/(dx[i+1]-dx[i])
+            nd.sb = (bmag[k + 1] - b) / da;
+            spsi = (bpsi[k + 1] - p) / da;
+        } else {
+            nd.sden = 0.0; nd.sb = 0.0;
+        }
+        if (TIER == 0) {
+            nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0; nd.u3 = 0.0;
+        } else if (info.poly_angle) {
+            // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
+            const double r = spsi * kDegToRad;
+            double sp, cp, s2p, c2p;
+            sincos(p * kDegToRad, &sp, &cp);
+            sincos(2.0 * (p * kDegToRad), &s2p, &c2p);
+            nd.u0 = sp * sp;
+            nd.u1 = s2p * r;
+            nd.u2 = c2p * (r * r);
+            nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
+        } else {
+            nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = 0.0;
+        }
+        nodes[k] = nd;
+        const double fn = sqrt(d) * kPlasma;       // :96
+        pf2[k] = fn * fn;                          // :136 numerator
+        gb[k] = kGyro * b;                         // :157 numerator
+    }
+    __syncthreads();
     // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
-    const double a0 = nodes[0].alt;
-    const double span = nodes[K - 1].alt - a0;
+    const double a0 = uniform(nodes[0].alt);
+    const double span = uniform(nodes[K - 1].alt) - a0;
     info.a0 = a0;
     info.uniform = (!ragged && K > 1 && step0 > 0.0) ? 1 : 0;
     info.inv_step = info.uniform ? 1.0 / step0 : 0.0;
@@ -386,28 +415,25 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     return info;
 }
 
-// Segment of np.interp for abscissa z: alt[j] <= z < alt[j+1], clamped to [0, K-1].
-__device__ __forceinline__ int locate(const Node* __restrict__ nodes, const unsigned short* __restrict__ hint,
-                                      const BlockInfo& info, double z) {
-    const int K = info.K;
+// First guess of np.interp's segment for abscissa z (exact after fix_segment).
+__device__ __forceinline__ int guess_segment(const unsigned short* __restrict__ hint, const BlockInfo& info,
+                                             double z) {
     int j;
     if (info.uniform) {
         j = (int)((z - info.a0) * info.inv_step);
-        j = j < 0 ? 0 : (j > K - 1 ? K - 1 : j);
+        j = j < 0 ? 0 : (j > info.K - 1 ? info.K - 1 : j);
     } else {
         int bucket = (int)((z - info.a0) * info.inv_w);
         bucket = bucket < 0 ? 0 : (bucket > kHintBuckets - 1 ? kHintBuckets - 1 : bucket);
         j = hint[bucket];
     }
-    while (j > 0 && z < nodes[j].alt) --j;
-    while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
     return j;
 }
 
 // mu' at abscissa offset dz >= 0 inside the segment that starts at node nd.
 template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_hz, double f2, double cX,
-                                            double cY, bool small_angle) {
+                                            double cY2, bool poly_angle) {
     double mu, mup;
     if (TIER == 0) {
 #pragma clang fp contract(off)
@@ -430,19 +456,18 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             index_unmagnetised(X, &mu, &mup);
         } else {
             const double b = nd.sb * dz + nd.b;
-            const double Y = b * cY;                   // cY = g_p / f
-            const double d = nd.u2 * dz;               // angle turned since the node [rad]
-            double sd, cd;
-            if (small_angle) {
-                const double d2 = d * d;
-                sd = d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0)));
-                cd = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0));
+            const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
+            double S2, C2;
+            if (poly_angle) {
+                S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
+                C2 = 1.0 - S2;
             } else {
-                sincos(d, &sd, &cd);
+                double s, c;
+                sincos(nd.u0 + nd.u1 * dz, &s, &c);
+                S2 = s * s;
+                C2 = c * c;
             }
-            const double s = nd.u0 * cd + nd.u1 * sd;
-            const double c = nd.u1 * cd - nd.u0 * sd;
-            index_fast<MODE>(X, Y, s, c, &mu, &mup);
+            index_fast<MODE>(X, Y2, S2, C2, &mu, &mup);
         }
     }
     return mup;
@@ -450,6 +475,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 
 // ---------------------------------------------------------------------------------------
 // S7-S11 for grid points [i0, i1) of one pair; returns this wave's partial sum (all lanes).
+// The multiplier loads of iteration n+1 are issued before the arithmetic of iteration n.
 // ---------------------------------------------------------------------------------------
 template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes,
@@ -457,39 +483,61 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                                                   const BlockInfo& info, const double* __restrict__ mult,
                                                   int n_points, int i0, int i1, double f_hz, double f2,
                                                   double h_refl, int lane) {
+    const int K = info.K;
     const double a0 = info.a0;
-    const double span = h_refl - a0;               // :413 (critical_height - aalt[0])
-    const double cX = (kPlasma * kPlasma) / f2;
+    const double span = uniform(h_refl - a0);      // :413 (critical_height - aalt[0])
+    const double cX = uniform((kPlasma * kPlasma) / f2);
     const double cY = kGyro / f_hz;
-    const bool small_angle = info.small_angle != 0;
+    const double cY2 = uniform(cY * cY);
+    const bool poly_angle = info.poly_angle != 0;
+    const int last = n_points - 1;
     double acc = 0.0;
-    for (int i = i0 + lane; i < i1; i += 64) {
+    int i = i0 + lane;
+    double m0 = 0.0, m1 = 0.0;
+    if (i < i1) {
+        m0 = mult[i];
+        m1 = mult[i < last ? i + 1 : last];
+    }
+    while (i < i1) {
+        // prefetch the next iteration's grid values; clamped, never conditional, so that the
+        // compiler can count outstanding loads (s_waitcnt vmcnt(2)) instead of draining them
+        const int inext = i + 64;
+        const int ic = inext < last ? inext : last;
+        const double n0 = mult[ic];
+        const double n1 = mult[ic < last ? ic + 1 : last];
         double z, dh;
         if (TIER == 0) {
 #pragma clang fp contract(off)
-            z = mult[i] * span + a0;               // :413
-            dh = kBackoff;                         // :415-416 last thickness
-            if (i + 1 < n_points) dh = (mult[i + 1] * span + a0) - z;
+            z = m0 * span + a0;                    // :413
+            dh = (i < last) ? (m1 * span + a0) - z : kBackoff;     // :415-416
         } else {
-            const double m0 = mult[i];
             z = __builtin_fma(m0, span, a0);
-            dh = kBackoff;
-            if (i + 1 < n_points) dh = (mult[i + 1] - m0) * span;
+            dh = (i < last) ? (m1 - m0) * span : kBackoff;
         }
-        const int j = locate(nodes, hint, info, z);
-        const Node nd = nodes[j];
+        // segment of np.interp: alt[j] <= z < alt[j+1]; the guess is almost always right
+        int j = guess_segment(hint, info, z);
+        Node nd = nodes[j];
+        const double an = nodes[j + 1].alt;        // node K is a +inf sentinel
+        if (__builtin_expect(__any((j > 0 && z < nd.alt) || z >= an), 0)) {
+            while (j > 0 && z < nodes[j].alt) --j;
+            while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+            nd = nodes[j];
+        }
         double dz = z - nd.alt;
         if (dz < 0.0) dz = 0.0;                    // z below the first level: left value
-        const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY, small_angle);
+        const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY2, poly_angle);
         const double term = mup * dh;              // :288
         if (term == term) acc = acc + term;        // nansum
+        i = inext;
+        m0 = n0;
+        m1 = n1;
     }
     return wave_sum(acc);
 }
 
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
-                                          const double* pf2, const unsigned short* hint,
+                                          const double* pf2, const double* gb, const unsigned short* hint,
                                           const BlockInfo& info, long long prof_local, int block_in_prof) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -504,10 +552,11 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
         double result = qnan();
         bool reflects = false;
         if (!info.bad) {
-            const double f_hz = a.freq[f] * 1e6;               // :491
-            const double f2 = f_hz * f_hz;                     // f**2
+            const double f_hz = uniform(a.freq[f] * 1e6);      // :491
+            const double f2 = uniform(f_hz * f_hz);            // f**2
             double h;
-            reflects = reflection_height<MODE>(nodes, pf2, info.K, f_hz, f2, lane, &h);
+            reflects = reflection_height<MODE>(nodes, pf2, gb, info.K, f_hz, f2, lane, &h);
+            h = uniform(h);
             if (reflects) {
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
@@ -524,9 +573,10 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 const double cX = (kPlasma * kPlasma) / f2, cY = kGyro / f_hz;
                 double term = 0.0;
                 if (c == C - 1) {
+                    const bool poly = info.poly_angle != 0;
                     const double mup = info.unmag
-                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY, true)
-                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY, true);
+                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly)
+                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly);
                     term = mup * kBackoff;
                     if (!(term == term)) term = 0.0;
                 }
@@ -549,12 +599,13 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 }  // namespace
 
 template <int TIER, int THREADS>
-__global__ __launch_bounds__(THREADS) void vfo_kernel(const KArgs a) {
+__global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_alt = (int)a.n_alt;
-    Node* nodes = reinterpret_cast<Node*>(smem);
-    double* pf2 = reinterpret_cast<double*>(smem + (size_t)n_alt * sizeof(Node));
-    unsigned short* hint = reinterpret_cast<unsigned short*>(pf2 + n_alt);
+    Node* nodes = reinterpret_cast<Node*>(smem);                        // n_alt + 1 nodes
+    double* pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
+    double* gb = pf2 + n_alt;
+    unsigned short* hint = reinterpret_cast<unsigned short*>(gb + n_alt);
     double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
                                             kHintBuckets * sizeof(unsigned short));
 
@@ -569,15 +620,15 @@ __global__ __launch_bounds__(THREADS) void vfo_kernel(const KArgs a) {
 
     const BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
-        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, n_alt, nodes, pf2, hint, red);
+        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, n_alt, nodes, pf2, gb, hint, red);
     if (threadIdx.x == 0 && block_in_prof == 0) {
         if (info.bad) atomicOr(a.status, (unsigned)info.bad);
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
     }
     if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
 }
 
 // Chunked pairs: add the chunk sums in a fixed order, then the reference's 0 -> NaN and + min(alt).
@@ -610,8 +661,9 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
         } else {
             double s, c;
             sincos(psi[i] * kDegToRad, &s, &c);
-            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], Y[i], s, c, &mu, &mup);
-            else index_fast<PRHF_KMODE_X>(X[i], Y[i], s, c, &mu, &mup);
+            const double y = Y[i];
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], y * y, s * s, c * c, &mu, &mup);
+            else index_fast<PRHF_KMODE_X>(X[i], y * y, s * s, c * c, &mu, &mup);
         }
         mu_out[i] = mu;
         mup_out[i] = mup;

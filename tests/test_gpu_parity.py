@@ -190,10 +190,10 @@ def test_mixed_worklist_matches_separate_launches(lib):
     g = load_golden("g5_chapman64.npz")
     args = (g["freq"], g["den"][:24], g["bmag"][:24], g["bpsi"][:24], g["alt"])
     segs = [(0, 8, "O", 200), (8, 14, "X", 2000), (14, 20, "O", 2000), (20, 24, "X", 20000)]
-    mixed = lib.vertical_forward_operator_mixed(*args, segs)
+    mixed = lib.vertical_forward_operator_mixed(*args, segs, math=lib.MATH_FAITHFUL)
     for p0, p1, mode, n in segs:
         sep = lib.vertical_forward_operator(g["freq"], g["den"][p0:p1], g["bmag"][p0:p1], g["bpsi"][p0:p1],
-                                            g["alt"], mode, n)
+                                            g["alt"], mode, n, math=lib.MATH_FAITHFUL)
         assert np.array_equal(mixed[p0:p1], sep, equal_nan=True), (p0, p1, mode, n)
 
 
