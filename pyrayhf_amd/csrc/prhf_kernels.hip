@@ -126,9 +126,14 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 //   1/(2 mu D) = sign(D) / (2 sqrt(N D))  -> one rsqrt gives mu, 1/D and that factor
 //   Y dD/dY = -2h +- (beta + h^2/beta)      (from :244-247, using Y d(alpha)/dY = 4h^2 + 2 YL^2 (1-X)^2)
 //   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
+// index_fast_core leaves the mu > 1 cliff (:238) to the caller: *rad_out = fl(1 - q).  In vacuum
+// (X -> 0) mu is 1 to rounding, so the cliff must sit where the reference's does:
+//   sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) > 1 + 2^-52.
+constexpr double kRadCliff = 1.0000000000000002;
+
 template <int MODE>
-__device__ __forceinline__ void index_fast(double X, double Y2, double S2, double C2, double* mu_out,
-                                           double* mup_out) {
+__device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double C2, double* mu_out,
+                                                double* mup_out, double* rad_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double Xm1 = 1.0 - X;
@@ -152,10 +157,17 @@ __device__ __forceinline__ void index_fast(double X, double Y2, double S2, doubl
     const double two_X = X + X;
     const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + q * YdDdY;
     const double A = __builtin_copysign(0.5 * w, D);
-    double mup = mu - A * bracket;
-    // :238 mu > 1 -> NaN.  In vacuum (X -> 0) mu is 1 to rounding, so the cliff must sit where
-    // the reference's does: sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) > 1 + 2^-52.
-    if (1.0 - q > 1.0000000000000002) { mu = qnan(); mup = qnan(); }
+    *mu_out = mu;
+    *mup_out = mu - A * bracket;
+    *rad_out = 1.0 - q;
+}
+
+template <int MODE>
+__device__ __forceinline__ void index_fast(double X, double Y2, double S2, double C2, double* mu_out,
+                                           double* mup_out) {
+    double mu, mup, rad;
+    index_fast_core<MODE>(X, Y2, S2, C2, &mu, &mup, &rad);
+    if (rad > kRadCliff) { mu = qnan(); mup = qnan(); }        // :238
     *mu_out = mu;
     *mup_out = mup;
 }
@@ -492,7 +504,52 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     const bool poly_angle = info.poly_angle != 0;
     const int last = n_points - 1;
     double acc = 0.0;
-    int i = i0 + lane;
+    int first = i0;                                // first grid point of the next wave-iteration
+    if (TIER == 1 && !UNMAG && poly_angle && info.uniform) {
+        // Lean main loop of the common case (uniform altitude grid, slowly turning field):
+        // whole wave-iterations that neither touch the last grid point nor need lane masks,
+        // so there is no index clamping, no exec masking and the loop control is scalar.
+        // The wave-iterations that remain (at most three) go through the generic loop below.
+#pragma clang fp contract(fast)
+        first = uniform(first);
+        const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
+        const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
+        const int jmax = K - 1;
+        if (first + 128 <= full_end) {
+            const double* pm = mult + lane;
+            double m0 = pm[first], m1 = pm[first + 1];
+            for (; first + 128 <= full_end; first += 64) {
+                const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
+                const double z = __builtin_fma(m0, span, a0);              // :413
+                const double dh = (m1 - m0) * span;                        // :415
+                int j = (int)(m0 * kj);
+                j = min(max(j, 0), jmax);
+                const Node* pn = reinterpret_cast<const Node*>(reinterpret_cast<const char*>(nodes) +
+                                                               __umul24((unsigned)j, (unsigned)sizeof(Node)));
+                Node nd = pn[0];
+                const double an = pn[1].alt;                               // node K is a +inf sentinel
+                // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
+                asm volatile("" :: "v"(nd.den), "v"(nd.sden), "v"(nd.b), "v"(nd.sb), "v"(nd.u0), "v"(nd.u1),
+                             "v"(nd.u2), "v"(nd.u3));
+                if (__builtin_expect(__any(z < nd.alt || z >= an), 0)) {
+                    while (j > 0 && z < nodes[j].alt) --j;
+                    while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+                    nd = nodes[j];
+                }
+                const double dz = fmax(z - nd.alt, 0.0);                   // below the first level: left value
+                const double den = nd.sden * dz + nd.den;
+                const double b = nd.sb * dz + nd.b;
+                const double S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
+                double mu, mup, rad;
+                index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, 1.0 - S2, &mu, &mup, &rad);
+                const double term = mup * dh;                              // :288
+                acc += (rad <= kRadCliff && term == term) ? term : 0.0;    // :238, nansum
+                m0 = n0;
+                m1 = n1;
+            }
+        }
+    }
+    int i = first + lane;
     double m0 = 0.0, m1 = 0.0;
     if (i < i1) {
         m0 = mult[i];

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into profiles/<tag>.md (+ hbm_traffic.json).
+
+    python tools/summarize_profile.py gpurun_out/prof_r01_v2 r01_v2 [workload-key]
+
+Kernel time comes from `rocprofv3 --kernel-trace --stats`; counters from separate `--pmc`
+passes.  HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB
+units on this stack and, on gfx950, FETCH_SIZE reports half the bytes of a wide coalesced
+read - both the raw and the doubled figure are listed; the doubled one is the bound we quote.
+"""
+
+from __future__ import annotations
+
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    key = sys.argv[3] if len(sys.argv) > 3 else "X_20000_12500x256"
+    kernel = "vfo_kernel"
+    lines = [f"# rocprofv3 summary `{tag}`", "",
+             f"Source: `tools/profile.sh {tag}` on one MI355X (bench.py default workload `{key}`: "
+             "12 500 profiles x 256 freqs, X-mode, n_points = 20000, fast tier).", ""]
+
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    avg_ns = None
+    if stats:
+        lines += ["## Kernel trace (`--kernel-trace --stats`)", "",
+                  "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
+        for r in csv.DictReader(open(stats[0])):
+            lines.append(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | "
+                         f"{float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} | {float(r['Percentage']):.3f} |")
+            if kernel in r["Name"]:
+                avg_ns = float(r["AverageNs"])
+        lines.append("")
+    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if trace:
+        for r in csv.DictReader(open(trace[0])):
+            if kernel in r["Kernel_Name"]:
+                lines += [f"Dispatch: grid {r['Grid_Size_X']} threads, workgroup {r['Workgroup_Size_X']}, "
+                          f"LDS {r['LDS_Block_Size']} B/workgroup, VGPR {r['VGPR_Count']}, "
+                          f"SGPR {r['SGPR_Count']}, scratch {r['Scratch_Size']} B.", ""]
+                break
+
+    counters = collections.defaultdict(list)
+    for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(path)):
+            if kernel in r["Kernel_Name"]:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    if mean:
+        lines += ["## Counters (separate `--pmc` passes, mean per dispatch of the fused kernel)", "",
+                  "| counter | value |", "|---|---|"]
+        for k in sorted(mean):
+            lines.append(f"| {k} | {mean[k]:.6g} |")
+        lines.append("")
+
+    derived = []
+    record = {}
+    if avg_ns and "GRBM_GUI_ACTIVE" in mean:
+        clk = mean["GRBM_GUI_ACTIVE"] / 8 / (avg_ns * 1e-9) / 1e9
+        derived.append(f"* effective shader clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time = **{clk:.2f} GHz**")
+    if "SQ_ACTIVE_INST_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
+        busy = mean["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (mean["GRBM_GUI_ACTIVE"] / 8)
+        derived.append(f"* VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles = **{100*busy:.1f} %**")
+        record["valu_busy"] = busy
+    if "SQ_WAVE_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
+        occ = mean["SQ_WAVE_CYCLES"] * 4 / 1024 / (mean["GRBM_GUI_ACTIVE"] / 8)
+        derived.append(f"* mean resident waves per SIMD = SQ_WAVE_CYCLES x 4 / 1024 / kernel cycles = **{occ:.2f}**")
+    if "SQ_INSTS_VALU" in mean and "SQ_WAVES" in mean:
+        derived.append(f"* VALU instructions per wave = {mean['SQ_INSTS_VALU'] / mean['SQ_WAVES']:.4g}; "
+                       f"SALU {mean.get('SQ_INSTS_SALU', 0) / mean['SQ_WAVES']:.4g}; "
+                       f"LDS {mean.get('SQ_INSTS_LDS', 0) / mean['SQ_WAVES']:.4g}; "
+                       f"VMEM reads {mean.get('SQ_INSTS_VMEM_RD', 0) / mean['SQ_WAVES']:.4g}")
+    if "SQ_LDS_BANK_CONFLICT" in mean and "SQ_LDS_IDX_ACTIVE" in mean:
+        derived.append(f"* LDS bank-conflict cycles / LDS active cycles = "
+                       f"{100 * mean['SQ_LDS_BANK_CONFLICT'] / mean['SQ_LDS_IDX_ACTIVE']:.2f} %")
+    if "TCC_HIT_sum" in mean:
+        derived.append(f"* L2 hit rate = {100 * mean['TCC_HIT_sum'] / (mean['TCC_HIT_sum'] + mean['TCC_MISS_sum']):.2f} %")
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        raw = (mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+        corrected = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+        derived.append(f"* HBM traffic per launch: FETCH_SIZE {mean['FETCH_SIZE']:.0f} KiB + WRITE_SIZE "
+                       f"{mean['WRITE_SIZE']:.0f} KiB = {raw/1e6:.1f} MB raw; with the gfx950 x2 read correction "
+                       f"**{corrected/1e6:.1f} MB**")
+        if avg_ns:
+            derived.append(f"* HBM rate = {corrected / (avg_ns * 1e-9) / 1e9:.2f} GB/s "
+                           f"({100 * corrected / (avg_ns * 1e-9) / 8e12:.4f} % of 8 TB/s)")
+        record.update(hbm_bytes_per_launch=corrected, fetch_kib=mean["FETCH_SIZE"], write_kib=mean["WRITE_SIZE"],
+                      kernel_ms=avg_ns / 1e6 if avg_ns else None, source=f"profiles/{tag}.md")
+    if derived:
+        lines += ["## Derived", ""] + derived + [""]
+
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", f"{tag}.md"), "w") as fh:
+        fh.write("\n".join(lines))
+    if record:
+        path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = record
+        with open(path, "w") as fh:
+            json.dump(data, fh, indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
