@@ -65,6 +65,23 @@ def cpu_baseline(freq, alt, den, bmag, bpsi, mode, n_points, budget_s=20.0):
                       f"oracle/vfo_numpy.py single process, {dt:.1f} s"}
 
 
+def cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points):
+    """The fused plain-C restatement (oracle/vfo_oracle.c) on every host core: a stronger
+    CPU baseline than the reference's unfused NumPy path.  None when the library is not built."""
+    from oracle import vfo_c
+    if not vfo_c.available():
+        return None
+    cores = vfo_c.threads()
+    vfo_c.virtual_heights_batch(freq, den[:cores], bmag[:cores], bpsi[:cores], alt, mode, 200)      # warm-up
+    n = min(den.shape[0], 4 * cores)
+    t0 = time.perf_counter()
+    vfo_c.virtual_heights_batch(freq, den[:n], bmag[:n], bpsi[:n], alt, mode, n_points)
+    dt = time.perf_counter() - t0
+    return {"value": n * freq.size / dt, "unit": "integrals/s", "cores": cores, "kind": "port",
+            "sample": f"{n} profiles x {freq.size} freqs, {mode}-mode n_points={n_points}, "
+                      f"oracle/vfo_oracle.c OpenMP x{cores}, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,8 +214,18 @@ def main():
                                         "ms_per_call": 1e3 * dt1, "integrals_per_s": f1.size / dt1,
                                         "kernel_ms": ctx.last_kernel_ms()}
 
+        if world == 1 and not args.no_single_profile:
+            # the same batch handed over as host NumPy buffers (pageable): H2D + kernel + D2H
+            library.vertical_forward_operator(freq, den[:64], bmag[:64], bpsi[:64], alt, mode, n_points, math=math)
+            t2 = time.perf_counter()
+            library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
+            dt2 = time.perf_counter() - t2
+            result["host_buffers"] = {"integrals_per_s": p_gpu * n_freq / dt2, "ms_per_call": 1e3 * dt2,
+                                      "note": "PCIe-inclusive (pageable host memory in and out); never `value`"}
+
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(freq, alt, den[:16], bmag[:16], bpsi[:16], mode, n_points)
+            result["cpu_baseline_fused_c"] = cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points)
         print(json.dumps(result), flush=True)
 
     if world > 1:

@@ -49,7 +49,8 @@ extern "C" {
 
 /* arithmetic tiers, prhf_ctx_set_math (see DESIGN.md "Arithmetic tiers") */
 #define PRHF_MATH_FAITHFUL 0  /* reference operation order, IEEE divide/sqrt, no contraction */
-#define PRHF_MATH_FAST     1  /* shared reciprocals / rsqrt, contracted; X-mode error <= 1e-9 relative */
+#define PRHF_MATH_FAST     1  /* reduced algebra, rsqrt + Newton, contracted; X-mode error <= 1e-9 relative */
+#define PRHF_MATH_AUTO     2  /* per slice: faithful for O mode (ill conditioned), fast for X mode; the default */
 
 typedef struct prhf_ctx prhf_ctx;
 
@@ -77,7 +78,7 @@ int prhf_ctx_destroy(prhf_ctx* ctx);
  * Pass NULL to return to the context's stream. */
 int prhf_ctx_set_stream(prhf_ctx* ctx, void* hip_stream);
 
-/* Select the arithmetic tier (PRHF_MATH_*), default PRHF_MATH_FAITHFUL. */
+/* Select the arithmetic tier (PRHF_MATH_*), default PRHF_MATH_AUTO. */
 int prhf_ctx_set_math(prhf_ctx* ctx, int level);
 
 /*

@@ -12,12 +12,12 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprhf.so")
+LIB_PATH = os.environ.get("PRHF_LIB") or os.path.join(_HERE, "libprhf.so")   # PRHF_LIB: A/B builds
 
 OK, EINVAL, ENEGDEN, EPEAK0, EHIP, ENOMEM = 0, -1, -2, -3, -4, -5
 MODE_O, MODE_X = 0, 1
 FLAG_DEVICE_PTRS, FLAG_ASYNC = 0x1, 0x2
-MATH_FAITHFUL, MATH_FAST = 0, 1
+MATH_FAITHFUL, MATH_FAST, MATH_AUTO = 0, 1, 2
 ABI_VERSION = 1
 
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -53,7 +53,7 @@ struct prhf_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int math = PRHF_MATH_FAITHFUL;
+    int math = PRHF_MATH_AUTO;
     DevBuf arena;     // staged host inputs + output
     DevBuf partial;   // chunk sums
     DevBuf altmin;    // per-profile min(alt) for chunked slices
@@ -137,6 +137,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     a.n_alt = n_alt;
     a.n_segs = n_segs;
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
+    int launch_tier = 0;
     for (int i = 0; i < n_segs; ++i) {
         const prhf_segment& u = segs[i];
         if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
@@ -154,6 +155,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.out_off = u.out_offset;
         s.mode = u.mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
         s.n_points = u.n_points;
+        s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
+        launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq);
         s.block_begin = blocks;
         const long long P = u.prof_end - u.prof_begin;
@@ -220,7 +223,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(prhf::launch_vfo(a, blocks, c->math == PRHF_MATH_FAST ? 1 : 0, prhf::lds_bytes_for(n_alt), c->stream));
+    HIP_TRY(prhf::launch_vfo(a, blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     c->status_pending = true;
@@ -305,7 +308,8 @@ int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream) {
 
 int prhf_ctx_set_math(prhf_ctx* c, int level) {
     if (!c) return fail(PRHF_EINVAL, "null context");
-    if (level != PRHF_MATH_FAITHFUL && level != PRHF_MATH_FAST) return fail(PRHF_EINVAL, "unknown math tier");
+    if (level != PRHF_MATH_FAITHFUL && level != PRHF_MATH_FAST && level != PRHF_MATH_AUTO)
+        return fail(PRHF_EINVAL, "unknown math tier");
     c->math = level;
     return PRHF_OK;
 }

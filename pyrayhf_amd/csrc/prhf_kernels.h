@@ -12,12 +12,16 @@
 #define PRHF_STATUS_NEGDEN 0x1
 #define PRHF_STATUS_PEAK0  0x2
 
+#ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
+#endif
 #define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
-#define PRHF_RED_DOUBLES 64         // block-reduction scratch (8 rows x waves)
+#define PRHF_RED_DOUBLES 128        // block-reduction scratch (8 rows x up to 16 waves)
 #define PRHF_NODE_BYTES 80          // one staged bottomside level
+#ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
+#endif
 
 namespace prhf {
 
@@ -33,7 +37,7 @@ struct SegDev {
     int chunks;                      // wave-sized work items per pair
     int chunk_len;                   // grid points per chunk (multiple of 64)
     int blocks_per_prof;
-    int pad_;
+    int tier;                        // 0 faithful, 1 fast (read by the mixed-tier kernel)
 };
 
 struct KArgs {
@@ -60,6 +64,7 @@ inline size_t lds_bytes_for(long long n_alt) {
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes);
+// tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,

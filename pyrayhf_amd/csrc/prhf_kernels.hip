@@ -82,6 +82,20 @@ __device__ __forceinline__ double rsqrt_cubic(double x) {
     return __builtin_fma(y * e, p, y);                     // y (1 + e/2 + 3 e^2/8)
 }
 
+// One Newton step instead: 2^-48 (measured).  Enough for X mode, whose answer is conditioned
+// like its inputs (the reference's own +-1 ulp response is 3e-11); not used for O mode.
+__device__ __forceinline__ double rsqrt_newton(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double t = x * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);                   // y (1 + e/2)
+}
+
+template <int MODE>
+__device__ __forceinline__ double rsqrt_tier(double x) {
+    return MODE == PRHF_KMODE_O ? rsqrt_cubic(x) : rsqrt_newton(x);
+}
+
 // ---------------------------------------------------------------------------------------
 // Appleton-Hartree group index, reference operation order (library.py:194-256).
 // ---------------------------------------------------------------------------------------
@@ -126,33 +140,35 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 //   1/(2 mu D) = sign(D) / (2 sqrt(N D))  -> one rsqrt gives mu, 1/D and that factor
 //   Y dD/dY = -2h +- (beta + h^2/beta)      (from :244-247, using Y d(alpha)/dY = 4h^2 + 2 YL^2 (1-X)^2)
 //   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
+// YL^2 = Y2 - Y2 S2 (absolute error 1e-16 Y2: harmless, YL^2 only enters through alpha and t).
 // index_fast_core leaves the mu > 1 cliff (:238) to the caller: *rad_out = fl(1 - q).  In vacuum
 // (X -> 0) mu is 1 to rounding, so the cliff must sit where the reference's does:
 //   sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) > 1 + 2^-52.
 constexpr double kRadCliff = 1.0000000000000002;
 
 template <int MODE>
-__device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double C2, double* mu_out,
+__device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double* mu_out,
                                                 double* mup_out, double* rad_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double Xm1 = 1.0 - X;
-    const double Xm12 = Xm1 * Xm1;
-    const double YL2 = Y2 * C2;
-    const double h = 0.5 * (Y2 * S2);
+    const double YT2 = Y2 * S2;
+    const double YL2 = Y2 - YT2;                               // Y^2 cos^2 psi
+    const double h = 0.5 * YT2;
     const double h2 = h * h;
-    const double alpha = h2 + YL2 * Xm12;
-    const double rbeta = rsqrt_cubic(alpha);
+    const double t = YL2 * Xm1;
+    const double alpha = h2 + t * Xm1;
+    const double rbeta = rsqrt_tier<MODE>(alpha);
     const double beta = alpha * rbeta;
     const double D = (Xm1 - h) + sgn * beta;
     const double XXm1 = X * Xm1;
     const double N = D - XXm1;
-    const double w = rsqrt_cubic(N * D);                       // NaN when mu^2 < 0 (:233)
+    const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
     const double Nw = N * w;
-    double mu = __builtin_fabs(Nw);
+    const double mu = __builtin_fabs(Nw);
     const double rD = Nw * w;
     const double q = XXm1 * rD;
-    const double dDdX = -sgn * ((YL2 * Xm1) * rbeta) - 1.0;    // :241-242
+    const double dDdX = -sgn * (t * rbeta) - 1.0;              // :241-242
     const double YdDdY = sgn * (h2 * rbeta + beta) - 2.0 * h;
     const double two_X = X + X;
     const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + q * YdDdY;
@@ -163,10 +179,9 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
 }
 
 template <int MODE>
-__device__ __forceinline__ void index_fast(double X, double Y2, double S2, double C2, double* mu_out,
-                                           double* mup_out) {
+__device__ __forceinline__ void index_fast(double X, double Y2, double S2, double* mu_out, double* mup_out) {
     double mu, mup, rad;
-    index_fast_core<MODE>(X, Y2, S2, C2, &mu, &mup, &rad);
+    index_fast_core<MODE>(X, Y2, S2, &mu, &mup, &rad);
     if (rad > kRadCliff) { mu = qnan(); mup = qnan(); }        // :238
     *mu_out = mu;
     *mup_out = mup;
@@ -469,17 +484,14 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
         } else {
             const double b = nd.sb * dz + nd.b;
             const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
-            double S2, C2;
+            double S2;
             if (poly_angle) {
                 S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
-                C2 = 1.0 - S2;
             } else {
-                double s, c;
-                sincos(nd.u0 + nd.u1 * dz, &s, &c);
-                S2 = s * s;
-                C2 = c * c;
+                const double sn = sin(nd.u0 + nd.u1 * dz);
+                S2 = sn * sn;
             }
-            index_fast<MODE>(X, Y2, S2, C2, &mu, &mup);
+            index_fast<MODE>(X, Y2, S2, &mu, &mup);
         }
     }
     return mup;
@@ -515,7 +527,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
         const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
         const int jmax = K - 1;
-        if (first + 128 <= full_end) {
+        if (first + 128 <= full_end && span >= 0.0) {         // span < 0: left clamp, generic loop
             const double* pm = mult + lane;
             double m0 = pm[first], m1 = pm[first + 1];
             for (; first + 128 <= full_end; first += 64) {
@@ -536,12 +548,12 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                     while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
                     nd = nodes[j];
                 }
-                const double dz = fmax(z - nd.alt, 0.0);                   // below the first level: left value
+                const double dz = z - nd.alt;                              // >= 0: span >= 0 and alt[j] <= z
                 const double den = nd.sden * dz + nd.den;
                 const double b = nd.sb * dz + nd.b;
                 const double S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
                 double mu, mup, rad;
-                index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, 1.0 - S2, &mu, &mup, &rad);
+                index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &rad);
                 const double term = mup * dh;                              // :288
                 acc += (rad <= kRadCliff && term == term) ? term : 0.0;    // :238, nansum
                 m0 = n0;
@@ -656,6 +668,25 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 }  // namespace
 
 template <int TIER, int THREADS>
+__device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
+                                          unsigned short* hint, double* red, long long prof_local,
+                                          int block_in_prof) {
+    const long long p = sg.prof_begin + prof_local;
+    const BlockInfo info = stage_profile<TIER, THREADS>(
+        a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
+        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
+    if (threadIdx.x == 0 && block_in_prof == 0) {
+        if (info.bad) atomicOr(a.status, (unsigned)info.bad);
+        if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
+    }
+    if (sg.mode == PRHF_KMODE_O)
+        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+    else
+        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+}
+
+// TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
+template <int TIER_SEL, int THREADS>
 __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_alt = (int)a.n_alt;
@@ -673,19 +704,11 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     const long long lb = bid - sg.block_begin;
     const long long prof_local = lb / sg.blocks_per_prof;
     const int block_in_prof = (int)(lb % sg.blocks_per_prof);
-    const long long p = sg.prof_begin + prof_local;
 
-    const BlockInfo info = stage_profile<TIER, THREADS>(
-        a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
-        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, n_alt, nodes, pf2, gb, hint, red);
-    if (threadIdx.x == 0 && block_in_prof == 0) {
-        if (info.bad) atomicOr(a.status, (unsigned)info.bad);
-        if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
-    }
-    if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+    if (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
+        run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+        run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof);
 }
 
 // Chunked pairs: add the chunk sums in a fixed order, then the reference's 0 -> NaN and + min(alt).
@@ -716,11 +739,10 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
             if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(X[i], Y[i], psi[i], &mu, &mup);
             else index_faithful<PRHF_KMODE_X>(X[i], Y[i], psi[i], &mu, &mup);
         } else {
-            double s, c;
-            sincos(psi[i] * kDegToRad, &s, &c);
+            const double sn = sin(psi[i] * kDegToRad);
             const double y = Y[i];
-            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], y * y, s * s, c * c, &mu, &mup);
-            else index_fast<PRHF_KMODE_X>(X[i], y * y, s * s, c * c, &mu, &mup);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], y * y, sn * sn, &mu, &mup);
+            else index_fast<PRHF_KMODE_X>(X[i], y * y, sn * sn, &mu, &mup);
         }
         mu_out[i] = mu;
         mup_out[i] = mup;
@@ -752,8 +774,10 @@ hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_b
     if (n_blocks <= 0) return hipSuccess;
     if (tier == 0)
         hipLaunchKernelGGL((vfo_kernel<0, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
-    else
+    else if (tier == 1)
         hipLaunchKernelGGL((vfo_kernel<1, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((vfo_kernel<2, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (int s = 0; s < a.n_segs; ++s) {
@@ -793,11 +817,14 @@ hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, lo
 
 hipError_t configure_kernels(size_t max_lds_bytes) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
+                             reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
+                             reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>)};
+    for (const void* k : kernels) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace prhf

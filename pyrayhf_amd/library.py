@@ -24,11 +24,12 @@ from . import _native, logger
 __all__ = [
     "constants", "den2freq", "freq2den", "find_X", "find_Y", "smooth_nonuniform_grid",
     "vertical_to_magnetic_angle", "find_mu_mup", "vertical_forward_operator",
-    "vertical_forward_operator_mixed", "last_kernel_ms", "MATH_FAITHFUL", "MATH_FAST",
+    "vertical_forward_operator_mixed", "last_kernel_ms", "MATH_FAITHFUL", "MATH_FAST", "MATH_AUTO",
 ]
 
 MATH_FAITHFUL = _native.MATH_FAITHFUL   # reference operation order, IEEE divide / sqrt
-MATH_FAST = _native.MATH_FAST           # shared reciprocals, rotation sin/cos, FMA contraction
+MATH_FAST = _native.MATH_FAST           # reduced algebra, rsqrt + Newton, FMA contraction
+MATH_AUTO = _native.MATH_AUTO           # per slice: faithful for 'O', fast for 'X' (default)
 
 
 # ----------------------------------------------------------------------------------------
@@ -88,11 +89,9 @@ _mult_cache = {}
 
 
 def _default_math(mode_code, math):
-    """O mode is ill conditioned near reflection and keeps the reference's operation order;
-    X mode (conditioning ~1e-11) takes the fast tier.  DESIGN.md "Arithmetic tiers"."""
-    if math is not None:
-        return int(math)
-    return MATH_FAITHFUL if mode_code == _native.MODE_O else MATH_FAST
+    """Default MATH_AUTO: O mode is ill conditioned near reflection and keeps the reference's
+    operation order; X mode (conditioning ~1e-11) takes the fast tier.  DESIGN.md section 5."""
+    return MATH_AUTO if math is None else int(math)
 
 
 def find_mu_mup(X, Y, bpsi, mode, *, device=None, math=None):
@@ -275,9 +274,7 @@ def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, dev
     if not segs:
         return out
     ctx = _native.context(device)
-    # one tier per launch: faithful unless every slice is X mode (or the caller chooses)
-    all_x = all(sg.mode == _native.MODE_X for sg in segs)
-    ctx.set_math(_default_math(_native.MODE_X if all_x else _native.MODE_O, math))
+    ctx.set_math(_default_math(None, math))       # MATH_AUTO: each slice in its mode's tier, one launch
     # the library writes only the rows its segments cover: stage `out` through the call
     rc = ctx.vfo_worklist(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                           n_prof, n_alt, n_alt, n_alt if a.ndim == 2 else 0, mult.ctypes.data, mult.size,

@@ -1,0 +1,118 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
+properties (the oracle cannot run them in full: config 4 is ~4 core-days of NumPy):
+
+* a shard evaluated alone equals the same rows of the full batch, bit for bit;
+* the NaN mask equals the reflection criterion evaluated on the host with the same IEEE
+  operations (`library.py:381-399`);
+* every finite virtual height lies above min(alt) and below a physical bound;
+* two launches are bit-identical (fixed summation order, no atomics on the data path);
+* a random sample of profiles agrees with the oracles under the parity rule.
+"""
+
+import zlib
+
+import numpy as np
+import pytest
+
+from parity import assert_masks, assert_x_mode, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CP, GP = 8.97866275, 2.799249247e10
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pyrayhf_amd import library
+    return library
+
+
+def reflecting_mask(freq_mhz, den, bmag, mode):
+    """library.py:381-399 on the host, profile by profile (running max reaches 1 below the peak)."""
+    out = np.zeros((den.shape[0], freq_mhz.size), dtype=bool)
+    f = freq_mhz * 1e6
+    for p in range(den.shape[0]):
+        k = int(np.argmax(den[p]))
+        X = (np.sqrt(den[p, :k]) * CP) ** 2 / f[:, None] ** 2
+        cond = X if mode == "O" else X + GP * bmag[p, :k] / f[:, None]
+        out[p] = cond.max(axis=1) >= 1.0
+    return out
+
+
+def checksum(a):
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8))
+
+
+def test_config3_10000_profiles_o_mode(lib):
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
+    freq = synth.sounder_frequencies(3)
+    vh = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 200)
+    assert vh.shape == (10000, 174)
+    # determinism
+    again = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 200)
+    assert checksum(vh) == checksum(again)
+    # shard invariance
+    part = lib.vertical_forward_operator(freq, den[2500:5000], bmag[2500:5000], bpsi[2500:5000], alt, "O", 200)
+    assert np.array_equal(part, vh[2500:5000], equal_nan=True)
+    # NaN mask: escaping frequencies are NaN; a reflecting one is NaN only if the profile bottom is
+    # already above cutoff (all terms NaN, library.py:288-290)
+    refl = reflecting_mask(freq, den, bmag, "O")
+    fin = np.isfinite(vh)
+    assert not (fin & ~refl).any()
+    odd = refl & ~fin
+    x0 = (np.sqrt(den[:, :1]) * CP) ** 2 / (freq[None, :] * 1e6) ** 2
+    assert np.all(x0[odd] >= 1.0)
+    assert 0.45 < fin.mean() < 0.60
+    # physical bounds
+    assert np.all(vh[fin] > alt.min()) and np.all(vh[fin] < 5000.0)
+    # oracle on a random sample
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(10000, size=8, replace=False))
+    want = orc.virtual_heights_batch(freq, den[pick], bmag[pick], bpsi[pick], alt, "O", 200)
+    assert_masks(vh[pick], want)
+    err, ok = rel_err(vh[pick], want)
+    assert np.mean(err[ok] <= 1e-6) >= 0.95 and err.max() <= 5e-4
+
+
+def test_config4_shard_x_mode_20000(lib):
+    from oracle import vfo_c
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(100000, 20260004, rows=slice(0, 12500))
+    freq = synth.sounder_frequencies(4)
+    vh = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 20000)
+    assert vh.shape == (12500, 256)
+    part = lib.vertical_forward_operator(freq, den[5000:5100], bmag[5000:5100], bpsi[5000:5100], alt, "X", 20000)
+    assert np.array_equal(part, vh[5000:5100], equal_nan=True)
+    refl = reflecting_mask(freq, den, bmag, "X")
+    fin = np.isfinite(vh)
+    assert not (fin & ~refl).any()
+    assert (refl & ~fin).mean() < 1e-3
+    assert np.all(vh[fin] >= alt.min()) and np.all(vh[fin] < 5000.0)
+    # virtual height grows with frequency within one layer trace more often than not (sanity, not physics proof)
+    if vfo_c.available():
+        pick = [7, 4242, 9000, 12499]
+        want = vfo_c.virtual_heights_batch(freq, den[pick], bmag[pick], bpsi[pick], alt, "X", 20000)
+        assert_x_mode(vh[pick], want, tol=1e-9)
+
+
+def test_config5_mixed_worklist(lib):
+    """Config 5's slice pattern at a fifth of its profile count (10 000 x 512, one launch)."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=slice(0, 50000, 5))
+    freq = synth.sounder_frequencies(5)
+    segs = [(0, 4000, "O", 200), (4000, 7000, "X", 2000), (7000, 9000, "O", 2000), (9000, 10000, "X", 20000)]
+    vh = lib.vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segs)
+    assert vh.shape == (10000, 512)
+    for p0, p1, mode, n in segs:
+        sl = slice(p0, min(p1, p0 + 200))
+        sep = lib.vertical_forward_operator(freq, den[sl], bmag[sl], bpsi[sl], alt, mode, n)
+        assert np.array_equal(sep, vh[sl], equal_nan=True), (p0, mode, n)
+        refl = reflecting_mask(freq, den[sl], bmag[sl], mode)
+        assert not (np.isfinite(vh[sl]) & ~refl).any()
+    want = orc.virtual_heights_batch(freq[::8], den[4000:4003], bmag[4000:4003], bpsi[4000:4003], alt, "X", 2000)
+    got = lib.vertical_forward_operator(freq[::8], den[4000:4003], bmag[4000:4003], bpsi[4000:4003], alt, "X", 2000)
+    assert_x_mode(got, want)
+    assert_x_mode(vh[4000:4003, ::8], want)
