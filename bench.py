@@ -71,11 +71,11 @@ def cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points):
     from oracle import vfo_c
     if not vfo_c.available():
         return None
-    cores = vfo_c.threads()
-    vfo_c.virtual_heights_batch(freq, den[:cores], bmag[:cores], bpsi[:cores], alt, mode, 200)      # warm-up
+    cores = min(vfo_c.threads(), 16)          # the GPU box's CPU share for one GPU
+    vfo_c.virtual_heights_batch(freq, den[:cores], bmag[:cores], bpsi[:cores], alt, mode, 200, n_threads=cores)
     n = min(den.shape[0], 4 * cores)
     t0 = time.perf_counter()
-    vfo_c.virtual_heights_batch(freq, den[:n], bmag[:n], bpsi[:n], alt, mode, n_points)
+    vfo_c.virtual_heights_batch(freq, den[:n], bmag[:n], bpsi[:n], alt, mode, n_points, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": n * freq.size / dt, "unit": "integrals/s", "cores": cores, "kind": "port",
             "sample": f"{n} profiles x {freq.size} freqs, {mode}-mode n_points={n_points}, "
@@ -185,6 +185,8 @@ def main():
                        "n_alt": int(alt.size), "math": args.math or "default",
                        "parallelism": f"profile shards x{world}, all_gather of vh rows" if world > 1 else "single GPU"},
             "reflecting_fraction": float(np.isfinite(vh).mean()),
+            "workgroups_per_cu": ctx.occupancy(alt.size, _native.MATH_FAST if mode == "X" and math is None
+                                               else (math or _native.MATH_FAITHFUL)),
             "kernel_ms": k_ms,
             "roofline": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

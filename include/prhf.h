@@ -127,6 +127,10 @@ int prhf_vfo_worklist_f64(prhf_ctx* ctx,
 int prhf_mu_mup_f64(prhf_ctx* ctx, const double* X, const double* Y, const double* psi_deg, int64_t n,
                     int32_t mode, double* mu_out, double* mup_out, uint32_t flags);
 
+/* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
+ * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
+int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);
+
 /* Wait for everything enqueued on the context; returns PRHF_ENEGDEN / PRHF_EPEAK0 if a
  * kernel flagged bad input since the last sync. */
 int prhf_sync(prhf_ctx* ctx);

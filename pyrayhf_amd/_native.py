@@ -54,6 +54,8 @@ _PROTOTYPES = {
     "prhf_mu_mup_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_uint32]),
+    "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                      ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "prhf_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
@@ -163,6 +165,11 @@ class Context:
 
     def mu_mup(self, X, Y, psi, n, mode, mu, mup, flags):
         return self._lib.prhf_mu_mup_f64(self._h, X, Y, psi, n, mode, mu, mup, flags)
+
+    def occupancy(self, n_alt, math):
+        n = ctypes.c_int32(0)
+        raise_for(self._lib.prhf_occupancy(self._h, int(n_alt), int(math), ctypes.byref(n)))
+        return n.value
 
     def sync(self):
         return self._lib.prhf_sync(self._h)

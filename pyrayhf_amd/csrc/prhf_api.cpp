@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
             return fail(PRHF_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-constexpr long long kTargetWaves = 8192;   // ~1.3x the waves resident at 3 blocks per CU
+long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
 constexpr long long kMaxAlt = 1600;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
@@ -251,6 +252,10 @@ int prhf_device_count(int* n) {
 
 int prhf_ctx_create(int device, prhf_ctx** out) {
     if (!out) return fail(PRHF_EINVAL, "null pointer");
+    if (const char* tw = std::getenv("PRHF_TARGET_WAVES")) {      // tuning knob, see DESIGN.md 4.1
+        const long long v = std::atoll(tw);
+        if (v >= 64) kTargetWaves = v;
+    }
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -370,6 +375,16 @@ int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double*
         HIP_TRY(hipMemcpyAsync(mup_out, dMup, bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return PRHF_OK;
+}
+
+int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {
+    if (!c || !workgroups_per_cu) return fail(PRHF_EINVAL, "null pointer");
+    if (n_alt < 1 || n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    int n = 0;
+    HIP_TRY(prhf::query_occupancy(math, prhf::lds_bytes_for(n_alt), &n));
+    *workgroups_per_cu = n;
     return PRHF_OK;
 }
 

@@ -64,6 +64,7 @@ inline size_t lds_bytes_for(long long n_alt) {
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes);
+hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words

@@ -37,8 +37,8 @@ constexpr double kPolyAngle = 3e-4;                 // rad per segment below whi
 
 // One bottomside level.  u0..u3 depend on the tier and (fast tier) on the profile:
 //   faithful:            u0 = psi [deg], u1 = d(psi)/dz [deg/km]
-//   fast, small turning: sin^2(psi(z)) = u0 + dz*(u1 + dz*(u2 + dz*u3)) inside the segment
-//   fast, large turning: u0 = psi [rad], u1 = d(psi)/dz [rad/km]
+//   fast, segment turning psi by < kPolyAngle: sin^2(psi(z)) = u0 + dz*(u1 + dz*(u2 + dz*u3)), pad = 0
+//   fast, other segments:                     u0 = psi [rad], u1 = d(psi)/dz [rad/km],          pad = 1
 struct __attribute__((aligned(16))) Node {
     double alt, den, sden, b, sb, u0, u1, u2, u3, pad;
 };
@@ -333,51 +333,10 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         info.bad = PRHF_STATUS_PEAK0;
         return info;
     }
-    // ---- phase 2a: per-profile flags that decide the node contents -------------------------
+    // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
-    double bmax = 0.0, turn = 0.0;
-    int neg = 0, ragged = 0;
-    for (int k = tid; k < K; k += THREADS) {
-        bmax = fmax(bmax, fabs(bmag[k]));
-        neg |= (den[k] < 0.0) ? 1 : 0;
-        if (k + 1 < K) {
-            turn = fmax(turn, fabs(bpsi[k + 1] - bpsi[k]) * kDegToRad);
-            ragged |= (fabs((alt[k + 1] - alt[k]) - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
-        }
-    }
-    bmax = wave_max(bmax);
-    turn = wave_max(turn);
-    neg = __any(neg) ? 1 : 0;
-    ragged = __any(ragged) ? 1 : 0;
-    if (lane == 0) {
-        red[4 * W + wave] = bmax;
-        red[5 * W + wave] = (double)neg;
-        red[6 * W + wave] = turn;
-        red[7 * W + wave] = (double)ragged;
-    }
-    __syncthreads();
-    bmax = red[4 * W];
-    neg = (int)red[5 * W];
-    turn = red[6 * W];
-    ragged = (int)red[7 * W];
-#pragma unroll
-    for (int w = 1; w < W; ++w) {
-        bmax = fmax(bmax, red[4 * W + w]);
-        neg |= (int)red[5 * W + w];
-        turn = fmax(turn, red[6 * W + w]);
-        ragged |= (int)red[7 * W + w];
-    }
-    bmax = uniform(bmax);
-    turn = uniform(turn);
-    neg = uniform(neg);
-    ragged = uniform(ragged);
-    if (neg) info.bad = PRHF_STATUS_NEGDEN;        // library.py:93-94
-    // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
-    // at the lowest frequency and the strongest field; the node maximum bounds the sampled
-    // maximum from above and equals it unless |B| < ~4e-18 T (DESIGN.md, "Deviations").
-    info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    info.poly_angle = (turn < kPolyAngle) ? 1 : 0;
-    // ---- phase 2b: nodes (values, np.interp slopes), f_N^2, g_p B -----------------------------
+    double bmax = 0.0;
+    int neg = 0, ragged = 0, trig = 0;
     for (int k = tid; k <= K; k += THREADS) {
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
@@ -388,36 +347,74 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         }
         const double a = alt[k], d = den[k], b = bmag[k], p = bpsi[k];
         nd.alt = a; nd.den = d; nd.b = b; nd.pad = 0.0;
-        double spsi = 0.0;
+        double spsi = 0.0, turn = 0.0;
         if (k + 1 < K) {
             const double da = alt[k + 1] - a;
+            const double dp = bpsi[k + 1] - p;
             nd.sden = (den[k + 1] - d) / da;       // numpy arr_interp: (dy[i+1]-dy[i])/(dx[i+1]-dx[i])
             nd.sb = (bmag[k + 1] - b) / da;
-            spsi = (bpsi[k + 1] - p) / da;
+            spsi = dp / da;
+            turn = fabs(dp) * kDegToRad;
+            ragged |= (fabs(da - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
         } else {
             nd.sden = 0.0; nd.sb = 0.0;
         }
         if (TIER == 0) {
             nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0; nd.u3 = 0.0;
-        } else if (info.poly_angle) {
+        } else if (turn < kPolyAngle) {
             // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
             const double r = spsi * kDegToRad;
-            double sp, cp, s2p, c2p;
+            double sp, cp;
             sincos(p * kDegToRad, &sp, &cp);
-            sincos(2.0 * (p * kDegToRad), &s2p, &c2p);
+            const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
             nd.u0 = sp * sp;
             nd.u1 = s2p * r;
             nd.u2 = c2p * (r * r);
             nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
-        } else {
+        } else {                                   // this segment turns the field too far for the cubic
             nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = 0.0;
+            nd.pad = 1.0;
+            trig = 1;
         }
         nodes[k] = nd;
         const double fn = sqrt(d) * kPlasma;       // :96
         pf2[k] = fn * fn;                          // :136 numerator
         gb[k] = kGyro * b;                         // :157 numerator
+        bmax = fmax(bmax, fabs(b));
+        neg |= (d < 0.0) ? 1 : 0;
+    }
+    bmax = wave_max(bmax);
+    neg = __any(neg) ? 1 : 0;
+    ragged = __any(ragged) ? 1 : 0;
+    trig = __any(trig) ? 1 : 0;
+    if (lane == 0) {
+        red[4 * W + wave] = bmax;
+        red[5 * W + wave] = (double)neg;
+        red[6 * W + wave] = (double)trig;
+        red[7 * W + wave] = (double)ragged;
     }
     __syncthreads();
+    bmax = red[4 * W];
+    neg = (int)red[5 * W];
+    trig = (int)red[6 * W];
+    ragged = (int)red[7 * W];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+        bmax = fmax(bmax, red[4 * W + w]);
+        neg |= (int)red[5 * W + w];
+        trig |= (int)red[6 * W + w];
+        ragged |= (int)red[7 * W + w];
+    }
+    bmax = uniform(bmax);
+    neg = uniform(neg);
+    trig = uniform(trig);
+    ragged = uniform(ragged);
+    if (neg) info.bad = PRHF_STATUS_NEGDEN;        // library.py:93-94
+    // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
+    // at the lowest frequency and the strongest field; the node maximum bounds the sampled
+    // maximum from above and equals it unless |B| < ~4e-18 T (DESIGN.md, "Deviations").
+    info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
+    info.poly_angle = trig ? 0 : 1;                // every segment uses the sin^2 cubic
     // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
     const double a0 = uniform(nodes[0].alt);
     const double span = uniform(nodes[K - 1].alt) - a0;
@@ -485,7 +482,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             const double b = nd.sb * dz + nd.b;
             const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
             double S2;
-            if (poly_angle) {
+            if (poly_angle || nd.pad == 0.0) {         // per segment; poly_angle: true for the whole profile
                 S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
             } else {
                 const double sn = sin(nd.u0 + nd.u1 * dz);
@@ -813,6 +810,16 @@ hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, lo
     else
         hipLaunchKernelGGL(mu_mup_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup);
     return hipGetLastError();
+}
+
+// Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
+hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu) {
+    constexpr int THREADS = PRHF_BLOCK_THREADS;
+    if (tier == 0)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vfo_kernel<0, THREADS>, THREADS, lds_bytes);
+    if (tier == 1)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vfo_kernel<1, THREADS>, THREADS, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vfo_kernel<2, THREADS>, THREADS, lds_bytes);
 }
 
 hipError_t configure_kernels(size_t max_lds_bytes) {

@@ -125,6 +125,22 @@ def test_find_mu_mup_device_op(lib, math):
     np.testing.assert_allclose(mup[ok], s["X_mup"][ok], rtol=1e-4)
 
 
+def test_field_angle_jump_mixes_cubic_and_trig_segments(lib):
+    """A profile whose field angle jumps at two levels: those segments take the sincos path, the
+    others the per-segment sin^2 cubic; the fast tier must still agree with the faithful one."""
+    g = load_golden("g5_chapman64.npz")
+    bpsi = g["bpsi"][:6].copy()
+    bpsi[:, 40:] += 1.5                  # 1.5 degree step between levels 39 and 40
+    bpsi[:, 120:] -= 0.7
+    for alt in (g["alt"], np.cumsum(np.where(np.arange(g["alt"].size) % 7 == 0, 1.3, 1.0)) + 79.0):
+        slow = lib.vertical_forward_operator(g["freq"], g["den"][:6], g["bmag"][:6], bpsi, alt, "X", 2000,
+                                             math=lib.MATH_FAITHFUL)
+        fast = lib.vertical_forward_operator(g["freq"], g["den"][:6], g["bmag"][:6], bpsi, alt, "X", 2000,
+                                             math=lib.MATH_FAST)
+        assert_x_mode(fast, slow, tol=1e-9)
+        assert np.isfinite(fast).mean() > 0.3
+
+
 def test_edge_cases_g7(lib):
     g = load_golden("g7_edges.npz")
     names = sorted({k[: -len("_n_points")] for k in g if k.endswith("_n_points")})
