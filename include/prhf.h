@@ -127,6 +127,29 @@ int prhf_vfo_worklist_f64(prhf_ctx* ctx,
 int prhf_mu_mup_f64(prhf_ctx* ctx, const double* X, const double* Y, const double* psi_deg, int64_t n,
                     int32_t mode, double* mu_out, double* mup_out, uint32_t flags);
 
+/*
+ * Virtual heights from already-regridded arrays.  Replaces: find_vh (reference library.py:259-293):
+ * vh[r] = nansum_c(mu'(X,Y,psi)[r,c] * dh[r,c]), exact 0 -> NaN, + alt_min.  X, Y, psi_deg, dh are
+ * (n_rows, n_cols) row-major; the isotropic test spans the whole array as in find_mu_mup.  Synchronous.
+ */
+int prhf_find_vh_f64(prhf_ctx* ctx, const double* X, const double* Y, const double* psi_deg, const double* dh,
+                     int64_t n_rows, int64_t n_cols, double alt_min, int32_t mode, double* vh_out,
+                     uint32_t flags);
+
+/*
+ * The un-fused first half of the operator for ONE profile.  Replaces: regrid_to_nonuniform_grid
+ * (reference library.py:324-438): peak truncation, reflection heights, stretched altitudes and the
+ * profile sampled on them.  freq_hz in Hz (as the reference's function takes it); every output is
+ * (n_freq, n_points) row-major: the reference's dict entries 'freq', 'den', 'bmag', 'bpsi', 'dist',
+ * 'alt', 'crit_height' (float64) and 'ind' (int64).  IEEE arithmetic in the reference's order: the
+ * outputs are bit-identical to NumPy's.  Synchronous; returns PRHF_ENEGDEN / PRHF_EPEAK0 on bad input.
+ */
+int prhf_regrid_f64(prhf_ctx* ctx, const double* freq_hz, int64_t n_freq, const double* den, const double* bmag,
+                    const double* bpsi, const double* alt, int64_t n_alt, const double* multiplier,
+                    int32_t n_points, int32_t mode, double* out_freq, double* out_den, double* out_bmag,
+                    double* out_bpsi, double* out_dist, double* out_alt, double* out_crit, int64_t* out_ind,
+                    uint32_t flags);
+
 /* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
  * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
 int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);

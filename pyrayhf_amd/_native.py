@@ -54,6 +54,12 @@ _PROTOTYPES = {
     "prhf_mu_mup_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_uint32]),
+    "prhf_find_vh_f64": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 4 +
+                         [ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p,
+                          ctypes.c_uint32]),
+    "prhf_regrid_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 +
+                        [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 8 +
+                        [ctypes.c_uint32]),
     "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -165,6 +171,14 @@ class Context:
 
     def mu_mup(self, X, Y, psi, n, mode, mu, mup, flags):
         return self._lib.prhf_mu_mup_f64(self._h, X, Y, psi, n, mode, mu, mup, flags)
+
+    def find_vh(self, X, Y, psi, dh, n_rows, n_cols, alt_min, mode, vh, flags):
+        return self._lib.prhf_find_vh_f64(self._h, X, Y, psi, dh, n_rows, n_cols, float(alt_min), mode, vh, flags)
+
+    def regrid(self, freq_hz, n_freq, den, bmag, bpsi, alt, n_alt, mult, n_points, mode, outs, flags):
+        """outs: eight raw addresses in the order freq, den, bmag, bpsi, dist, alt, crit_height, ind."""
+        return self._lib.prhf_regrid_f64(self._h, freq_hz, n_freq, den, bmag, bpsi, alt, n_alt, mult, n_points,
+                                         mode, *outs, flags)
 
     def occupancy(self, n_alt, math):
         n = ctypes.c_int32(0)

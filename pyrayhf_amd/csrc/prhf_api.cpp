@@ -378,6 +378,104 @@ int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double*
     return PRHF_OK;
 }
 
+int prhf_find_vh_f64(prhf_ctx* c, const double* X, const double* Y, const double* psi_deg, const double* dh,
+                     int64_t n_rows, int64_t n_cols, double alt_min, int32_t mode, double* vh_out,
+                     uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!X || !Y || !psi_deg || !dh || !vh_out) return fail(PRHF_EINVAL, "null array pointer");
+    if (n_rows < 0 || n_cols < 0) return fail(PRHF_EINVAL, "bad shape");
+    if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "Mode must be O or X");
+    if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
+    if (n_rows == 0) return PRHF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    const int64_t n = n_rows * n_cols;
+    const double *dX = X, *dY = Y, *dP = psi_deg, *dD = dh;
+    double* dV = vh_out;
+    if (!dev) {
+        int rc = ensure(c, c->arena, (size_t)(4 * n + n_rows) * 8);
+        if (rc != PRHF_OK) return rc;
+        double* base = static_cast<double*>(c->arena.p);
+        const double* src[4] = {X, Y, psi_deg, dh};
+        for (int k = 0; k < 4 && n > 0; ++k)
+            HIP_TRY(hipMemcpyAsync(base + k * n, src[k], (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        dX = base; dY = base + n; dP = base + 2 * n; dD = base + 3 * n; dV = base + 4 * n;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_find_vh(dX, dY, dP, dD, n_rows, n_cols, alt_min,
+                                 mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
+                                 c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dV, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (!dev) HIP_TRY(hipMemcpyAsync(vh_out, dV, (size_t)n_rows * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PRHF_OK;
+}
+
+int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const double* den, const double* bmag,
+                    const double* bpsi, const double* alt, int64_t n_alt, const double* multiplier,
+                    int32_t n_points, int32_t mode, double* out_freq, double* out_den, double* out_bmag,
+                    double* out_bpsi, double* out_dist, double* out_alt, double* out_crit, int64_t* out_ind,
+                    uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!freq_hz || !den || !bmag || !bpsi || !alt || !multiplier || !out_freq || !out_den || !out_bmag ||
+        !out_bpsi || !out_dist || !out_alt || !out_crit || !out_ind)
+        return fail(PRHF_EINVAL, "null array pointer");
+    if (n_freq < 1 || n_alt < 1 || n_alt > kMaxAlt || n_points < 1) return fail(PRHF_EINVAL, "bad shape");
+    if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "mode must be 'O' or 'X'");
+    if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    const size_t fn = (size_t)n_freq * (size_t)n_points;
+    prhf::RegridArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_freq = n_freq; a.n_alt = n_alt; a.n_points = n_points;
+    a.mode = mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
+    a.status = c->d_status;
+    double* base = nullptr;
+    if (dev) {
+        a.freq_hz = freq_hz; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = multiplier;
+        a.out_freq = out_freq; a.out_den = out_den; a.out_bmag = out_bmag; a.out_bpsi = out_bpsi;
+        a.out_dist = out_dist; a.out_alt = out_alt; a.out_crit = out_crit;
+        a.out_ind = reinterpret_cast<long long*>(out_ind);
+    } else {
+        const size_t in_elems = (size_t)n_freq + 4 * (size_t)n_alt + (size_t)n_points;
+        int rc = ensure(c, c->arena, (in_elems + 8 * fn) * 8);
+        if (rc != PRHF_OK) return rc;
+        base = static_cast<double*>(c->arena.p);
+        double* d_freq = base;
+        double* d_den = d_freq + n_freq;
+        double* d_bmag = d_den + n_alt;
+        double* d_bpsi = d_bmag + n_alt;
+        double* d_alt = d_bpsi + n_alt;
+        double* d_mult = d_alt + n_alt;
+        double* d_out = d_mult + n_points;
+        HIP_TRY(hipMemcpyAsync(d_freq, freq_hz, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_den, den, (size_t)n_alt * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_bmag, bmag, (size_t)n_alt * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, (size_t)n_alt * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_alt, alt, (size_t)n_alt * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mult, multiplier, (size_t)n_points * 8, hipMemcpyHostToDevice, c->stream));
+        a.freq_hz = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.mult = d_mult;
+        a.out_freq = d_out; a.out_den = d_out + fn; a.out_bmag = d_out + 2 * fn; a.out_bpsi = d_out + 3 * fn;
+        a.out_dist = d_out + 4 * fn; a.out_alt = d_out + 5 * fn; a.out_crit = d_out + 6 * fn;
+        a.out_ind = reinterpret_cast<long long*>(d_out + 7 * fn);
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_regrid(a, prhf::lds_bytes_for(n_alt), c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    c->status_pending = true;
+    if (!dev) {
+        double* host[7] = {out_freq, out_den, out_bmag, out_bpsi, out_dist, out_alt, out_crit};
+        double* devp[7] = {a.out_freq, a.out_den, a.out_bmag, a.out_bpsi, a.out_dist, a.out_alt, a.out_crit};
+        for (int k = 0; k < 7; ++k)
+            HIP_TRY(hipMemcpyAsync(host[k], devp[k], fn * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_ind, a.out_ind, fn * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    return prhf_sync(c);
+}
+
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {
     if (!c || !workgroups_per_cu) return fail(PRHF_EINVAL, "null pointer");
     if (n_alt < 1 || n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt out of range");

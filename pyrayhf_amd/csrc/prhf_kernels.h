@@ -71,6 +71,32 @@ hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_b
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
                          unsigned long long* absmax_scratch, unsigned long long* absmax_host,
                          double* mu, double* mup, hipStream_t stream);
+hipError_t launch_find_vh(const double* X, const double* Y, const double* psi, const double* dh, long long n_rows,
+                          long long n_cols, double alt_min, int mode, int tier,
+                          unsigned long long* absmax_scratch, unsigned long long* absmax_host, double* vh,
+                          hipStream_t stream);
+
+// Standalone regrid of one profile (library.py:324-438); all pointers are device memory.
+struct RegridArgs {
+    const double* freq_hz;
+    const double* den;
+    const double* bmag;
+    const double* bpsi;
+    const double* alt;
+    const double* mult;
+    double* out_freq;
+    double* out_den;
+    double* out_bmag;
+    double* out_bpsi;
+    double* out_dist;
+    double* out_alt;
+    double* out_crit;
+    long long* out_ind;
+    unsigned* status;
+    long long n_freq, n_alt;
+    int n_points, mode;
+};
+hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream);
 
 }  // namespace prhf
 

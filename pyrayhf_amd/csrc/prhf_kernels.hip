@@ -812,6 +812,144 @@ hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, lo
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Standalone find_vh (library.py:259-293): one wavefront per row of (n_rows, n_cols) arrays,
+// lanes stride the columns (coalesced), NaN terms skipped, 0 -> NaN, + alt_min.
+// ---------------------------------------------------------------------------------------
+template <int TIER>
+__global__ void find_vh_kernel(const double* __restrict__ X, const double* __restrict__ Y,
+                               const double* __restrict__ psi, const double* __restrict__ dh, long long n_rows,
+                               long long n_cols, double alt_min, int mode, int unmag, double* __restrict__ vh) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const long long base = row * n_cols;
+    double acc = 0.0;
+    for (long long i = lane; i < n_cols; i += 64) {
+        double mu, mup;
+        const double x = X[base + i], y = Y[base + i], p = psi[base + i];
+        if (unmag) {
+            index_unmagnetised(x, &mu, &mup);
+        } else if (TIER == 0) {
+            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(x, y, p, &mu, &mup);
+            else index_faithful<PRHF_KMODE_X>(x, y, p, &mu, &mup);
+        } else {
+            const double sn = sin(p * kDegToRad);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, sn * sn, &mu, &mup);
+            else index_fast<PRHF_KMODE_X>(x, y * y, sn * sn, &mu, &mup);
+        }
+        const double term = mup * dh[base + i];            // :288
+        if (term == term) acc = acc + term;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) vh[row] = (acc != 0.0) ? acc + alt_min : qnan();     // :290-292
+}
+
+hipError_t launch_find_vh(const double* X, const double* Y, const double* psi, const double* dh, long long n_rows,
+                          long long n_cols, double alt_min, int mode, int tier,
+                          unsigned long long* absmax_scratch, unsigned long long* absmax_host, double* vh,
+                          hipStream_t stream) {
+    const long long n = n_rows * n_cols;
+    if (n_rows <= 0) return hipSuccess;
+    int unmag = 0;
+    if (n > 0) {
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipError_t e = hipMemsetAsync(absmax_scratch, 0, 2 * sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, Y, n, absmax_scratch);
+        e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        double ymax;
+        __builtin_memcpy(&ymax, absmax_host, sizeof ymax);
+        unmag = (absmax_host[1] != 0 && ymax < kUnmagTol) ? 1 : 0;
+    }
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
+    if (tier == 0)
+        hipLaunchKernelGGL(find_vh_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
+                           alt_min, mode, unmag, vh);
+    else
+        hipLaunchKernelGGL(find_vh_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
+                           alt_min, mode, unmag, vh);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Standalone regrid_to_nonuniform_grid (library.py:324-438) for ONE profile: one workgroup per
+// frequency stages the profile, wave 0 finds the reflection height, all waves write the
+// (n_points) rows of the seven float64 outputs and the int64 index row.  IEEE arithmetic in the
+// reference's order: the outputs are bit-identical to NumPy's.
+// ---------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_alt = (int)a.n_alt;
+    Node* nodes = reinterpret_cast<Node*>(smem);
+    double* pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
+    double* gb = pf2 + n_alt;
+    unsigned short* hint = reinterpret_cast<unsigned short*>(gb + n_alt);
+    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
+                                            kHintBuckets * sizeof(unsigned short));
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const double one_mhz = 1.0;     // stage_profile only needs a frequency column for the isotropic test
+    const BlockInfo info = stage_profile<0, THREADS>(a.den, a.bmag, a.bpsi, a.alt, &one_mhz, 0, n_alt, nodes,
+                                                     pf2, gb, hint, red);
+    if (threadIdx.x == 0 && info.bad) atomicOr(a.status, (unsigned)info.bad);
+    const double f_hz = a.freq_hz[f];
+    double h = qnan();
+    int reflects = 0;
+    if (!info.bad) {
+        double hh;
+        const double f2 = f_hz * f_hz;
+        const bool ok = (a.mode == PRHF_KMODE_O)
+            ? reflection_height<PRHF_KMODE_O>(nodes, pf2, gb, info.K, f_hz, f2, lane, &hh)
+            : reflection_height<PRHF_KMODE_X>(nodes, pf2, gb, info.K, f_hz, f2, lane, &hh);
+        if (ok) { h = hh; reflects = 1; }
+    }
+    const int K = info.K;
+    const double a0 = info.bad ? 0.0 : info.a0;
+    const double span = h - a0;
+    const long long row = (long long)f * a.n_points;
+    for (int i = threadIdx.x; i < a.n_points; i += THREADS) {
+        const double z = a.mult[i] * span + a0;                              // :413 (NaN when escaping)
+        double dh = kBackoff;                                                // :415-416
+        if (i + 1 < a.n_points) dh = (a.mult[i + 1] * span + a0) - z;
+        double d = z, b = z, p = z;                                          // np.interp(NaN) = NaN
+        if (!info.bad && (reflects || K == 1)) {
+            int j = 0;
+            if (reflects) {
+                j = guess_segment(hint, info, z);
+                while (j > 0 && z < nodes[j].alt) --j;
+                while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+            }
+            const Node nd = nodes[j];
+            double dz = reflects ? z - nd.alt : 0.0;                         // K == 1: the single node
+            if (dz < 0.0) dz = 0.0;
+            d = nd.sden * dz + nd.den;                                       // :424-426
+            b = nd.sb * dz + nd.b;
+            p = nd.u1 * dz + nd.u0;
+        }
+        a.out_freq[row + i] = f_hz;
+        a.out_den[row + i] = d;
+        a.out_bmag[row + i] = b;
+        a.out_bpsi[row + i] = p;
+        a.out_dist[row + i] = dh;
+        a.out_alt[row + i] = z;
+        a.out_crit[row + i] = h;
+        a.out_ind[row + i] = i;
+    }
+}
+
+hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream) {
+    if (a.n_freq <= 0 || a.n_points <= 0) return hipSuccess;
+    hipLaunchKernelGGL(regrid_kernel<256>, dim3((unsigned)a.n_freq), dim3(256), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
 // Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;
@@ -826,7 +964,8 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;
     const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
-                             reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>)};
+                             reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
+                             reinterpret_cast<const void*>(&regrid_kernel<256>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
         if (e != hipSuccess) return e;

@@ -117,6 +117,51 @@ def find_mu_mup(X, Y, bpsi, mode, *, device=None, math=None):
     return mu.reshape(shape), mup.reshape(shape)
 
 
+def find_vh(X, Y, bpsi, dh, alt_min, mode, *, device=None, math=None):
+    """Virtual height from already-regridded arrays; the reference's ``find_vh`` (library.py:259-293).
+
+    ``X, Y, bpsi, dh``: ``(F, N)`` arrays; returns ``(F,)``: ``nansum(mu' * dh, axis=1)`` with an exact
+    zero mapped to NaN, plus ``alt_min``.  Default tier: faithful.
+    """
+    if mode not in _MODE_CODE:
+        raise ValueError("Mode must be O or X")                   # raised by find_mu_mup, library.py:225-226
+    X, Y, bpsi, dh = np.broadcast_arrays(*(np.asarray(a, dtype=np.float64) for a in (X, Y, bpsi, dh)))
+    if X.ndim != 2:
+        raise ValueError("X, Y, bpsi and dh must be 2-D (frequencies x grid points)")
+    x, y, p, d = (np.ascontiguousarray(a) for a in (X, Y, bpsi, dh))
+    vh = np.empty(x.shape[0], dtype=np.float64)
+    ctx = _native.context(device)
+    ctx.set_math(MATH_FAITHFUL if math is None else int(math))
+    _native.raise_for(ctx.find_vh(x.ctypes.data, y.ctypes.data, p.ctypes.data, d.ctypes.data, x.shape[0],
+                                  x.shape[1], alt_min, _MODE_CODE[mode], vh.ctypes.data, 0))
+    return vh
+
+
+def regrid_to_nonuniform_grid(f, n_e, b, bpsi, aalt, mode='O', n_points=200, dh=1e-6, *, device=None):
+    """Regrid one profile to the stretched per-frequency grid; the reference's function of the same
+    name (library.py:324-438), computed on the GPU.
+
+    ``f`` in **Hz**; returns the reference's dict of ``(F, N)`` arrays ``freq, den, bmag, bpsi, dist, alt,
+    crit_height`` (float64) and ``ind`` (int64), bit-identical to NumPy's.  As in the reference the
+    ``dh`` argument is ignored (it is overwritten with 1e-6 km, library.py:378).
+    """
+    code = _mode_code(mode)
+    fz = np.ascontiguousarray(np.atleast_1d(np.asarray(f)), dtype=np.float64)
+    d, bb, p, a = (np.ascontiguousarray(np.asarray(x), dtype=np.float64) for x in (n_e, b, bpsi, aalt))
+    if not (d.ndim == 1 and d.shape == bb.shape == p.shape == a.shape):
+        raise ValueError("n_e, b, bpsi and aalt must be 1-D arrays of one length")
+    mult = _multiplier(n_points)
+    shape = (fz.size, int(n_points))
+    names = ("freq", "den", "bmag", "bpsi", "dist", "alt", "crit_height")
+    out = {k: np.empty(shape, dtype=np.float64) for k in names}
+    out["ind"] = np.empty(shape, dtype=np.int64)
+    ctx = _native.context(device)
+    rc = ctx.regrid(fz.ctypes.data, fz.size, d.ctypes.data, bb.ctypes.data, p.ctypes.data, a.ctypes.data, d.size,
+                    mult.ctypes.data, int(n_points), code, [out[k].ctypes.data for k in names + ("ind",)], 0)
+    _native.raise_for(rc)
+    return out
+
+
 def _mode_code(mode):
     try:
         return _MODE_CODE[mode]
