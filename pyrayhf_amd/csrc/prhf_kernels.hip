@@ -494,6 +494,39 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
     return mup;
 }
 
+// One grid point per lane on the lean path of the fast tier (uniform altitude grid, every segment
+// on the sin^2 cubic, z >= alt[0], not the last grid point): returns mu' * dh, or 0 where the
+// reference's term is NaN (:233, :238, :288).
+template <int MODE>
+__device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double m0, double m1,
+                                            double span, double a0, double kj, double cX, double cY2) {
+#pragma clang fp contract(fast)
+    const double z = __builtin_fma(m0, span, a0);              // :413
+    const double dh = (m1 - m0) * span;                        // :415
+    int j = (int)(m0 * kj);
+    const Node* pn = reinterpret_cast<const Node*>(reinterpret_cast<const char*>(nodes) +
+                                                   __umul24((unsigned)j, (unsigned)sizeof(Node)));
+    Node nd = pn[0];
+    const double an = pn[1].alt;                               // node K is a +inf sentinel
+    // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
+    asm volatile("" :: "v"(nd.den), "v"(nd.sden), "v"(nd.b), "v"(nd.sb), "v"(nd.u0), "v"(nd.u1), "v"(nd.u2),
+                 "v"(nd.u3));
+    if (__builtin_expect(__any(z < nd.alt || z >= an), 0)) {   // restore np.interp's exact segment
+        while (j > 0 && z < nodes[j].alt) --j;
+        while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
+        nd = nodes[j];
+    }
+    const double dz = z - nd.alt;                              // >= 0: span >= 0 and alt[j] <= z
+    const double den = nd.sden * dz + nd.den;
+    const double b = nd.sb * dz + nd.b;
+    const double S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
+    double mu, mup, rad;
+    index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &rad);
+    // a NaN anywhere upstream makes rad NaN (it is 1 - X(1-X)/D with 1/D from the same rsqrt as mu),
+    // so one comparison covers :233, :238 and the nansum
+    return (rad <= kRadCliff) ? mup * dh : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------
 // S7-S11 for grid points [i0, i1) of one pair; returns this wave's partial sum (all lanes).
 // The multiplier loads of iteration n+1 are issued before the arithmetic of iteration n.
@@ -523,38 +556,23 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         first = uniform(first);
         const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
         const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
-        const int jmax = K - 1;
         if (first + 128 <= full_end && span >= 0.0) {         // span < 0: left clamp, generic loop
+            // 0 <= m <= 1 and span < alt[K-1] - a0, so (int)(m * kj) is already inside [0, K-2].
+            double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
+            asm volatile("" : "+v"(a0v));
             const double* pm = mult + lane;
             double m0 = pm[first], m1 = pm[first + 1];
-            for (; first + 128 <= full_end; first += 64) {
+            // two wave-iterations per trip so that the prefetch registers swap roles without moves
+            for (; first + 192 <= full_end; first += 128) {
                 const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
-                const double z = __builtin_fma(m0, span, a0);              // :413
-                const double dh = (m1 - m0) * span;                        // :415
-                int j = (int)(m0 * kj);
-                j = min(max(j, 0), jmax);
-                const Node* pn = reinterpret_cast<const Node*>(reinterpret_cast<const char*>(nodes) +
-                                                               __umul24((unsigned)j, (unsigned)sizeof(Node)));
-                Node nd = pn[0];
-                const double an = pn[1].alt;                               // node K is a +inf sentinel
-                // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
-                asm volatile("" :: "v"(nd.den), "v"(nd.sden), "v"(nd.b), "v"(nd.sb), "v"(nd.u0), "v"(nd.u1),
-                             "v"(nd.u2), "v"(nd.u3));
-                if (__builtin_expect(__any(z < nd.alt || z >= an), 0)) {
-                    while (j > 0 && z < nodes[j].alt) --j;
-                    while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
-                    nd = nodes[j];
-                }
-                const double dz = z - nd.alt;                              // >= 0: span >= 0 and alt[j] <= z
-                const double den = nd.sden * dz + nd.den;
-                const double b = nd.sb * dz + nd.b;
-                const double S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
-                double mu, mup, rad;
-                index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &rad);
-                const double term = mup * dh;                              // :288
-                acc += (rad <= kRadCliff && term == term) ? term : 0.0;    // :238, nansum
-                m0 = n0;
-                m1 = n1;
+                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
+                m0 = pm[first + 128];
+                m1 = pm[first + 129];
+                acc += lean_step<MODE>(nodes, K, n0, n1, span, a0v, kj, cX, cY2);
+            }
+            if (first + 128 <= full_end) {                     // odd wave-iteration left over
+                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
+                first += 64;
             }
         }
     }
