@@ -109,11 +109,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in the product path)")
+    # Rehearsal knob for a one-GPU box: PRHF_BENCH_BACKEND=gloo runs every rank on GPU 0 and gathers
+    # through host memory.  The driver's runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get("PRHF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
     p_gpu, n_freq, n_points, mode = args.profiles, args.freqs, args.n_points, args.mode
@@ -149,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _native.raise_for(ctx.sync())
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

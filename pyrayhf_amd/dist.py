@@ -52,8 +52,12 @@ def gather_rows(local, n_total, group=None):
         pad = torch.full((biggest - local.shape[0], width), float("nan"), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
     local = local.contiguous()
+    device = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()          # rehearsal on one GPU box: gloo gathers host tensors only
     buf = torch.empty((world * biggest, width), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, local, group=group)
+    buf = buf.to(device)
     if all(c == biggest for c in counts):
         return buf
     return torch.cat([buf[r * biggest: r * biggest + counts[r]] for r in range(world)], dim=0)

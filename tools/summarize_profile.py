@@ -79,6 +79,18 @@ def main():
                        f"SALU {mean.get('SQ_INSTS_SALU', 0) / mean['SQ_WAVES']:.4g}; "
                        f"LDS {mean.get('SQ_INSTS_LDS', 0) / mean['SQ_WAVES']:.4g}; "
                        f"VMEM reads {mean.get('SQ_INSTS_VMEM_RD', 0) / mean['SQ_WAVES']:.4g}")
+    if all(k in mean for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                               "SQ_INSTS_VALU_TRANS_F64")) and avg_ns:
+        # per-wave instruction counts x 64 lanes; an FMA is two flops
+        flops = 64 * (mean["SQ_INSTS_VALU_ADD_F64"] + mean["SQ_INSTS_VALU_MUL_F64"] +
+                      2 * mean["SQ_INSTS_VALU_FMA_F64"] + mean["SQ_INSTS_VALU_TRANS_F64"])
+        derived.append(f"* FP64 instructions per dispatch: add {mean['SQ_INSTS_VALU_ADD_F64']:.4g}, mul "
+                       f"{mean['SQ_INSTS_VALU_MUL_F64']:.4g}, fma {mean['SQ_INSTS_VALU_FMA_F64']:.4g}, "
+                       f"transcendental {mean['SQ_INSTS_VALU_TRANS_F64']:.4g} (wave instructions)")
+        derived.append(f"* executed FP64 rate = {flops / (avg_ns * 1e-9) / 1e12:.1f} TFLOP/s "
+                       f"(**{100 * flops / (avg_ns * 1e-9) / 78.6e12:.1f} %** of the 78.6 TFLOP/s vector peak; "
+                       f"an all-FMA stream would be needed for 100 %)")
+        record["fp64_tflops_executed"] = flops / (avg_ns * 1e-9) / 1e12
     if "SQ_LDS_BANK_CONFLICT" in mean and "SQ_LDS_IDX_ACTIVE" in mean:
         derived.append(f"* LDS bank-conflict cycles / LDS active cycles = "
                        f"{100 * mean['SQ_LDS_BANK_CONFLICT'] / mean['SQ_LDS_IDX_ACTIVE']:.2f} %")
