@@ -150,6 +150,29 @@ int prhf_regrid_f64(prhf_ctx* ctx, const double* freq_hz, int64_t n_freq, const 
                     double* out_bpsi, double* out_dist, double* out_alt, double* out_crit, int64_t* out_ind,
                     uint32_t flags);
 
+/*
+ * Residual rows of the fitting driver for n_prof candidate profiles against one observed trace.
+ * Replaces: the arithmetic of residual_VH (reference library.py:660-669) applied to a batch: modeled
+ * NaNs are replaced by max(nanmean|vh_model row|, 100), residual = vh_obs - vh_model, and
+ * cost[p] = sum_f residual[p,f]^2 (the objective of the brute-force search, library.py:794-798).
+ * vh_model (n_prof, n_freq) is normally the output of prhf_vfo_batch_f64 left on the device;
+ * residual_out or cost_out may be NULL.
+ */
+int prhf_residual_f64(prhf_ctx* ctx, const double* vh_model, const double* vh_obs, int64_t n_prof, int64_t n_freq,
+                      double* residual_out, double* cost_out, uint32_t flags);
+
+/*
+ * prhf_vfo_batch_f64 followed by prhf_residual_f64 in one call: the candidate profiles are staged once,
+ * the modeled traces never leave HBM between the two kernels.  vh_out may be NULL (only residuals / costs
+ * wanted); residual_out or cost_out may be NULL.  This is the whole inner loop of the reference's
+ * brute-force fit (minimize_parameters, library.py:794-798: one residual_VH call per grid node) as one launch.
+ */
+int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq, const double* den,
+                          const double* bmag, const double* bpsi, const double* alt, int64_t n_prof,
+                          int64_t n_alt, int64_t prof_stride_elems, int64_t alt_stride_elems,
+                          const double* multiplier, int32_t n_points, int32_t mode, const double* vh_obs,
+                          double* vh_out, double* residual_out, double* cost_out, uint32_t flags);
+
 /* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
  * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
 int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);

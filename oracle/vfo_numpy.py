@@ -201,3 +201,17 @@ def stage_capture(freq_mhz, den, bmag, bpsi, alt, mode, n_points):
         out.update(X=X, Y=Y, mu=mu, mup=mup,
                    vh=group_path(X, Y, cols["bpsi"], cols["dist"], np.min(alt), mode))
         return out
+
+
+def residual_rows(vh_obs, vh_model):
+    """Residual rows of the fitting driver for a (P, F) batch of modeled traces.
+
+    Restates reference library.py:660-669 (residual_VH) row by row: modeled NaNs are replaced by
+    max(nanmean(|vh_model|), 100), then residual = vh_obs - vh_model.  (The reference function
+    itself needs PyIRI and lmfit, which are not installed: parity for this row is unpinned.)
+    """
+    vh_model = np.array(vh_model, dtype=float, copy=True)
+    with np.errstate(all="ignore"):
+        for row in vh_model:
+            row[np.isnan(row)] = np.maximum(np.nanmean(np.abs(row)), 100)
+    return np.asarray(vh_obs, dtype=float)[None, :] - vh_model

@@ -60,6 +60,13 @@ _PROTOTYPES = {
     "prhf_regrid_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 +
                         [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 8 +
                         [ctypes.c_uint32]),
+    "prhf_residual_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "prhf_vfo_residual_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_uint32]),
     "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -179,6 +186,16 @@ class Context:
         """outs: eight raw addresses in the order freq, den, bmag, bpsi, dist, alt, crit_height, ind."""
         return self._lib.prhf_regrid_f64(self._h, freq_hz, n_freq, den, bmag, bpsi, alt, n_alt, mult, n_points,
                                          mode, *outs, flags)
+
+    def residual(self, vh_model, vh_obs, n_prof, n_freq, residual, cost, flags):
+        return self._lib.prhf_residual_f64(self._h, vh_model, vh_obs, n_prof, n_freq, residual or None,
+                                           cost or None, flags)
+
+    def vfo_residual(self, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride, alt_stride, mult,
+                     n_points, mode, vh_obs, vh, residual, cost, flags):
+        return self._lib.prhf_vfo_residual_f64(self._h, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt,
+                                               prof_stride, alt_stride, mult, n_points, mode, vh_obs,
+                                               vh or None, residual or None, cost or None, flags)
 
     def occupancy(self, n_alt, math):
         n = ctypes.c_int32(0)

@@ -104,6 +104,13 @@ void plan_slice(prhf::SegDev& s, long long n_freq) {
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
+// Optional second stage of a launch: residual rows against one observed trace (prhf_vfo_residual_f64).
+struct Residual {
+    const double* vh_obs;   // (n_freq)
+    double* residual;       // (n_prof, n_freq) or null
+    double* cost;           // (n_prof) or null
+};
+
 int status_to_code(unsigned bits) {
     if (bits & PRHF_STATUS_PEAK0)
         return fail(PRHF_EPEAK0, "density peak at index 0: no bottomside levels below the peak");
@@ -114,9 +121,11 @@ int status_to_code(unsigned bits) {
 int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, const double* bmag,
         const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt, int64_t prof_stride,
         int64_t alt_stride, const double* mult, int64_t mult_len, const prhf_segment* segs, int32_t n_segs,
-        double* out, uint32_t flags) {
+        double* out, uint32_t flags, const Residual* post = nullptr) {
     if (!c) return fail(PRHF_EINVAL, "null context");
-    if (!freq || !den || !bmag || !bpsi || !alt || !mult || !out || !segs)
+    if (!freq || !den || !bmag || !bpsi || !alt || !mult || !segs || (!out && !post))
+        return fail(PRHF_EINVAL, "null array pointer");
+    if (post && (!post->vh_obs || (!post->residual && !post->cost)))
         return fail(PRHF_EINVAL, "null array pointer");
     if (n_freq < 1 || n_prof < 0 || n_alt < 1) return fail(PRHF_EINVAL, "bad shape");
     if (n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt %lld exceeds the LDS-resident limit %lld",
@@ -189,8 +198,9 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         a.alt_stride = alt_stride;
     } else {
         const size_t n_alt_rows = alt_stride ? (size_t)n_prof : 1;
+        const size_t post_elems = post ? (size_t)n_freq + out_elems + (size_t)n_prof : 0;
         const size_t elems = (size_t)n_freq + 3 * (size_t)n_prof * n_alt + n_alt_rows * n_alt +
-                             (size_t)mult_len + out_elems;
+                             (size_t)mult_len + out_elems + post_elems;
         if ((rc = ensure(c, c->arena, elems * 8)) != PRHF_OK) return rc;
         double* base = static_cast<double*>(c->arena.p);
         double* d_freq = base;
@@ -223,14 +233,37 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         a.alt_stride = alt_stride ? n_alt : 0;
     }
 
+    double* vh_dev = a.out;
+    if (dev && post && !out) {                 // caller does not want the modeled trace: keep it in scratch
+        if ((rc = ensure(c, c->arena, out_elems * 8)) != PRHF_OK) return rc;
+        vh_dev = a.out = static_cast<double*>(c->arena.p);
+    }
+    const double* d_obs = post ? post->vh_obs : nullptr;
+    double* d_res = post ? post->residual : nullptr;
+    double* d_cost = post ? post->cost : nullptr;
+    if (post && !dev) {
+        double* p0 = d_out + out_elems;
+        HIP_TRY(hipMemcpyAsync(p0, post->vh_obs, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
+        d_obs = p0;
+        d_res = post->residual ? p0 + n_freq : nullptr;
+        d_cost = post->cost ? p0 + n_freq + out_elems : nullptr;
+    }
+
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(prhf::launch_vfo(a, blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+    if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     c->status_pending = true;
 
-    if (!dev && out_elems)
+    if (!dev && out_elems && out)
         HIP_TRY(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!dev && post) {
+        if (post->residual)
+            HIP_TRY(hipMemcpyAsync(post->residual, d_res, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
+        if (post->cost)
+            HIP_TRY(hipMemcpyAsync(post->cost, d_cost, (size_t)n_prof * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     if (flags & PRHF_FLAG_ASYNC) return PRHF_OK;
     return prhf_sync(c);
 }
@@ -341,6 +374,23 @@ int prhf_vfo_worklist_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
                           int32_t n_segs, double* vh_out, uint32_t flags) {
     return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
                multiplier, multiplier_len, segs, n_segs, vh_out, flags);
+}
+
+int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq, const double* den,
+                          const double* bmag, const double* bpsi, const double* alt, int64_t n_prof,
+                          int64_t n_alt, int64_t prof_stride_elems, int64_t alt_stride_elems,
+                          const double* multiplier, int32_t n_points, int32_t mode, const double* vh_obs,
+                          double* vh_out, double* residual_out, double* cost_out, uint32_t flags) {
+    prhf_segment seg;
+    seg.prof_begin = 0;
+    seg.prof_end = n_prof;
+    seg.mode = mode;
+    seg.n_points = n_points;
+    seg.mult_offset = 0;
+    seg.out_offset = 0;
+    Residual post{vh_obs, residual_out, cost_out};
+    return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
+               multiplier, n_points, &seg, 1, vh_out, flags, &post);
 }
 
 int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double* psi_deg, int64_t n,
@@ -474,6 +524,42 @@ int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const do
         HIP_TRY(hipMemcpyAsync(out_ind, a.out_ind, fn * 8, hipMemcpyDeviceToHost, c->stream));
     }
     return prhf_sync(c);
+}
+
+int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs, int64_t n_prof, int64_t n_freq,
+                      double* residual_out, double* cost_out, uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!vh_model || !vh_obs || (!residual_out && !cost_out)) return fail(PRHF_EINVAL, "null array pointer");
+    if (n_prof < 0 || n_freq < 1 || n_freq > (1 << 20)) return fail(PRHF_EINVAL, "bad shape");
+    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC)) return fail(PRHF_EINVAL, "unknown flag bits");
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    if ((flags & PRHF_FLAG_ASYNC) && !dev) return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC needs device pointers");
+    if (n_prof == 0) return PRHF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t pf = (size_t)n_prof * (size_t)n_freq;
+    const double *dM = vh_model, *dO = vh_obs;
+    double *dR = residual_out, *dC = cost_out;
+    if (!dev) {
+        int rc = ensure(c, c->arena, (2 * pf + (size_t)n_freq + (size_t)n_prof) * 8);
+        if (rc != PRHF_OK) return rc;
+        double* base = static_cast<double*>(c->arena.p);
+        HIP_TRY(hipMemcpyAsync(base, vh_model, pf * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(base + pf, vh_obs, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
+        dM = base; dO = base + pf;
+        dR = residual_out ? base + pf + n_freq : nullptr;
+        dC = cost_out ? base + 2 * pf + n_freq : nullptr;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_residual(dM, dO, n_prof, (int)n_freq, dR, dC, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (!dev) {
+        if (residual_out) HIP_TRY(hipMemcpyAsync(residual_out, dR, pf * 8, hipMemcpyDeviceToHost, c->stream));
+        if (cost_out) HIP_TRY(hipMemcpyAsync(cost_out, dC, (size_t)n_prof * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (flags & PRHF_FLAG_ASYNC) return PRHF_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PRHF_OK;
 }
 
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {

@@ -97,6 +97,9 @@ struct RegridArgs {
     int n_points, mode;
 };
 hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream);
+// residual / cost may be null
+hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,
+                           double* residual, double* cost, hipStream_t stream);
 
 }  // namespace prhf
 

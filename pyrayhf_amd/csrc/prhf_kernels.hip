@@ -968,6 +968,49 @@ hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stre
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Residual rows of the fitting driver (residual_VH, library.py:660-669): per candidate profile,
+// modeled NaNs are replaced by max(nanmean|vh_model|, 100) and residual = vh_obs - vh_model;
+// cost = sum of squares (what lmfit's brute-force grid search minimises, library.py:794-798).
+// One wavefront per candidate row.
+// ---------------------------------------------------------------------------------------
+__global__ void residual_kernel(const double* __restrict__ vh_model, const double* __restrict__ vh_obs,
+                                long long n_prof, int n_freq, double* __restrict__ residual,
+                                double* __restrict__ cost) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_prof) return;
+    const double* v = vh_model + row * n_freq;
+    double sum = 0.0, cnt = 0.0;
+    for (int f = lane; f < n_freq; f += 64) {
+        const double a = fabs(v[f]);
+        if (a == a) { sum += a; cnt += 1.0; }
+    }
+    sum = wave_sum(sum);
+    cnt = wave_sum(cnt);
+    // np.maximum(np.nanmean(|v|), 100): an all-NaN row has NaN mean and np.maximum propagates it (:664)
+    const double mean = (cnt > 0.0) ? sum / cnt : qnan();
+    const double fill = (mean == mean) ? fmax(mean, 100.0) : qnan();
+    double c = 0.0;
+    for (int f = lane; f < n_freq; f += 64) {
+        double m = v[f];
+        if (!(m == m)) m = fill;
+        const double r = vh_obs[f] - m;                        // :668
+        if (residual) residual[row * n_freq + f] = r;
+        c += r * r;
+    }
+    c = wave_sum(c);
+    if (lane == 0 && cost) cost[row] = c;
+}
+
+hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,
+                           double* residual, double* cost, hipStream_t stream) {
+    if (n_prof <= 0) return hipSuccess;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)((n_prof + 3) / 4)), dim3(256), 0, stream, vh_model, vh_obs,
+                       n_prof, n_freq, residual, cost);
+    return hipGetLastError();
+}
+
 // Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;

@@ -1,0 +1,77 @@
+"""Batched residual / brute-force driver against the oracle's restatement of
+reference library.py:660-669, and a self-consistency fit in the spirit of the reference's
+test_zero_residual_when_parameters_match (test_core.py:279-320)."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_residual_rows_match_the_oracle():
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import fitting
+    g = load_golden("g5_chapman64.npz")
+    freq = g["freq"][5:140:3]
+    obs = g["X_2000_vh"][3, 5:140:3].copy()
+    obs[np.isnan(obs)] = 250.0
+    res, cost = fitting.residual_VH_batch(freq, obs, g["den"][:16], g["bmag"][3], g["bpsi"][3], g["alt"], "X", 2000)
+    model = orc.virtual_heights_batch(freq, g["den"][:16], np.tile(g["bmag"][3], (16, 1)),
+                                      np.tile(g["bpsi"][3], (16, 1)), g["alt"], "X", 2000)
+    want = orc.residual_rows(obs, model)
+    assert res.shape == want.shape == (16, freq.size)
+    np.testing.assert_allclose(res, want, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(cost, (want ** 2).sum(axis=1), rtol=1e-9)
+    # the candidate that generated the observations has a ~zero residual where both reflect
+    both = np.isfinite(model[3])
+    assert np.max(np.abs(res[3][both])) < 1e-6
+
+
+def test_all_nan_candidate_gives_nan_cost_and_is_skipped():
+    from pyrayhf_amd import fitting
+    g = load_golden("g5_chapman64.npz")
+    freq = np.array([25.0, 30.0])                       # above every foF2: every candidate escapes
+    res, cost = fitting.residual_VH_batch(freq, np.array([300.0, 320.0]), g["den"][:4], g["bmag"][0], g["bpsi"][0],
+                                          g["alt"], "O", 100)
+    assert np.all(np.isnan(res)) and np.all(np.isnan(cost))          # np.maximum(nan, 100) = nan, library.py:664
+    with pytest.raises(ValueError):
+        fitting.brute_force_fit(freq, np.array([300.0, 320.0]), g["den"][:4], g["bmag"][0], g["bpsi"][0], g["alt"],
+                                "O", 100)
+
+
+def test_brute_force_recovers_the_generating_profile():
+    """Synthetic truth: a Chapman F2 layer; candidates scan hmF2 and the scale height around it."""
+    from pyrayhf_amd import fitting
+    alt = np.arange(80.0, 700.0, 1.0)
+
+    def layer(hm, h):
+        z = (alt - hm) / h
+        return 8e11 * np.exp(0.5 * (1 - z - np.exp(-z))) + 1e11 * np.exp(0.5 * (1 - (alt - 110) / 8 - np.exp(-(alt - 110) / 8)))
+
+    bmag = 4.5e-5 * ((6371.0 + 80.0) / (6371.0 + alt)) ** 3
+    bpsi = np.full(alt.size, 35.0)
+    hms, hs = np.arange(280.0, 321.0, 2.0), np.arange(40.0, 61.0, 2.0)
+    grid = [(hm, h) for hm in hms for h in hs]
+    den = np.array([layer(hm, h) for hm, h in grid])
+    truth = grid.index((300.0, 50.0))
+    freq = np.arange(2.0, 8.0, 0.25)
+    from pyrayhf_amd import library
+    obs = library.vertical_forward_operator(freq, den[truth], bmag, bpsi, alt, "O", 200)
+    obs_noisy = obs.copy()
+    obs_noisy[3] = np.nan                                # a missing sounding is filtered out (library.py:742)
+    best, cost, vh_best, f_used = fitting.brute_force_fit(freq[::-1], obs_noisy[::-1], den, bmag, bpsi, alt, "O", 200)
+    assert best == truth and cost[truth] < 1e-12 and f_used.size == freq.size - 1
+    assert np.all(np.diff(f_used) > 0)
+    assert cost.shape == (len(grid),) and np.sum(cost < 1.0) == 1
+
+
+def test_peak_density_from_trace_formulae():
+    from pyrayhf_amd import fitting, library
+    assert fitting.peak_density_from_trace(9.0) == library.freq2den(9.0e6) * 1.0001          # library.py:768
+    alt = np.arange(80.0, 700.0, 1.0)
+    bmag = np.full(alt.size, 4e-5)
+    fc = 4e-5 * 2.799249247e10
+    want = library.freq2den(np.sqrt(9.0e6 ** 2 - 9.0e6 * fc)) * 1.0001                       # library.py:774-778
+    assert fitting.peak_density_from_trace(9.0, "X", alt=alt, bmag=bmag, hmf2=300.0) == want
