@@ -1,0 +1,52 @@
+"""Host-side adapters either side of the operator."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from pyrayhf_amd import io as pio
+from pyrayhf_amd import library
+
+
+def test_oblique_to_vertical_identities():
+    # reference test_core.py:890-916
+    D = 600.0
+    p = np.array([900.0, 1100.0, 1500.0])
+    f_o = np.array([5.0, 10.0, 15.0])
+    f_v, h_v = pio.oblique_to_vertical(D, p, f_o)
+    Re_val = library.constants()[2]
+    dcurv = Re_val * (1.0 - np.cos((D / 2.0) / Re_val))
+    phi = np.arcsin(D / p)
+    assert np.allclose(f_v / f_o, np.cos(phi), rtol=1e-12, atol=1e-12)
+    assert np.allclose(h_v + dcurv, 0.5 * p * np.cos(phi), rtol=1e-12, atol=1e-12)
+    assert np.all(np.isfinite(f_v)) and np.all(np.isfinite(h_v)) and np.all(h_v >= 0)
+
+
+def test_input_dict_adapter_single_and_batch():
+    g = load_golden("g4_day_night.npz")
+    day = {k: g[f"Day_{k}"] for k in ("alt", "den", "bmag", "bpsi")}
+    day.update(year=2025, month=9, day=1, UT=0, F107=204, tlat=4.5, tlon=-150.0)     # generate_input_1D extras
+    night = {k: g[f"Night_{k}"][None, :] for k in ("alt", "den", "bmag", "bpsi")}    # un-squeezed arrays are accepted
+    alt, den, bmag, bpsi = pio.from_input_dict(day)
+    assert alt.shape == den.shape == (620,) and den.dtype == np.float64
+    alt2, den2, bmag2, bpsi2 = pio.from_input_dict([day, night])
+    assert alt2.shape == (620,) and den2.shape == bmag2.shape == bpsi2.shape == (2, 620)
+    assert np.array_equal(den2[1], g["Night_den"])
+    with pytest.raises(KeyError):
+        pio.from_input_dict({"alt": day["alt"]})
+    with pytest.raises(ValueError):
+        pio.from_input_dict({**day, "den": day["den"][:10]})
+
+
+def test_batch_npz_round_trip(tmp_path):
+    g = load_golden("g5_chapman64.npz")
+    path = tmp_path / "batch.npz"
+    pio.save_batch_npz(path, g["alt"], g["den"][:5], g["bmag"][:5], g["bpsi"][:5], freq=g["freq"], seed=20260001)
+    back = pio.load_batch_npz(path)
+    for k in ("alt", "freq"):
+        assert np.array_equal(back[k], g[k])
+    for k in ("den", "bmag", "bpsi"):
+        assert np.array_equal(back[k], g[k][:5])
+    assert int(back["meta"]["seed"]) == 20260001
+    with pytest.raises(ValueError):
+        pio.save_batch_npz(path, g["alt"][:-1], g["den"][:5], g["bmag"][:5], g["bpsi"][:5])
