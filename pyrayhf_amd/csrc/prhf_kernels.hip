@@ -503,7 +503,9 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
 #pragma clang fp contract(fast)
     const double z = __builtin_fma(m0, span, a0);              // :413
     const double dh = (m1 - m0) * span;                        // :415
-    int j = (int)(m0 * kj);
+    // 0 <= m <= 1 puts (int)(m * kj) inside [0, K-1]; the unsigned min only guards the LDS address
+    // against a caller-supplied multiplier outside [0, 1] (it also folds a negative index to K-1)
+    int j = (int)min((unsigned)(int)(m0 * kj), (unsigned)(K - 1));
     const Node* pn = reinterpret_cast<const Node*>(reinterpret_cast<const char*>(nodes) +
                                                    __umul24((unsigned)j, (unsigned)sizeof(Node)));
     Node nd = pn[0];

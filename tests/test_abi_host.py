@@ -66,3 +66,22 @@ def test_host_helpers_match_reference_known_answers():
         library.den2freq(np.array([-1.0]))
     assert library.vertical_to_magnetic_angle(60.0) == 30.0                             # test_core.py:210-220
     assert np.allclose(library.vertical_to_magnetic_angle(np.array([0.0, 45.0, 90.0])), [90.0, 45.0, 0.0])
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Entry points validate their arguments before touching the device: a null context is PRHF_EINVAL
+    with a thread-local message, and creating a context without a GPU is PRHF_EHIP (or EINVAL: no such
+    device) - never a silent success."""
+    lib = _native.load()
+    rc = lib.prhf_vfo_batch_f64(None, None, 0, None, None, None, None, 0, 0, 0, 0, None, 0, 0, None, 0)
+    assert rc == _native.EINVAL and b"context" in lib.prhf_last_error()
+    assert lib.prhf_sync(None) == _native.EINVAL
+    assert lib.prhf_mu_mup_f64(None, None, None, None, 0, 0, None, None, 0) == _native.EINVAL
+    assert lib.prhf_ctx_set_math(None, 0) == _native.EINVAL
+    import torch
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        rc = lib.prhf_ctx_create(0, ctypes.byref(h))
+        assert rc in (_native.EHIP, _native.EINVAL) and not h.value
+        assert lib.prhf_last_error()
+    assert lib.prhf_ctx_destroy(None) == _native.OK
