@@ -173,6 +173,24 @@ int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
                           const double* multiplier, int32_t n_points, int32_t mode, const double* vh_obs,
                           double* vh_out, double* residual_out, double* cost_out, uint32_t flags);
 
+/*
+ * Stratified Snell's-law ray tracing over a flat Earth for n_rays rays (one wavefront each).
+ * Replaces: trace_ray_cartesian_snells (reference library.py:1096-1268) with tan_from_mu_scalar
+ * (:1034-1062) and find_turning_point (:1065-1093).  Ray r has frequency freq_hz[r] [Hz], launch elevation
+ * elevation_deg[r] above the horizon and uses profile profile_index[r] (NULL: profile 0) of the
+ * (n_prof, n_alt) columns; a ground level at z = 0 is inserted when alt[0] > 0, as in the reference.
+ * out is (n_rays, 8): group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km (the
+ * reference's dict entries; its x_apex_km / z_apex_km equal the midpoint), then x and z of the turning
+ * point and the number of path nodes.  Rays that never turn give NaN (node count 0).  path_x / path_z
+ * (optional, (n_rays, path_stride), path_stride >= 2 n_alt + 1) receive the reference's 'x' and 'z'
+ * arrays padded with NaN.  Synchronous; PRHF_ENEGDEN on a negative density.
+ */
+int prhf_snell_cartesian_f64(prhf_ctx* ctx, const double* freq_hz, const double* elevation_deg,
+                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                             int64_t alt_stride_elems, int32_t mode, double* out, double* path_x, double* path_z,
+                             int64_t path_stride, uint32_t flags);
+
 /* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
  * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
 int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);

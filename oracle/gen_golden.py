@@ -245,8 +245,54 @@ def main():
         lib.vertical_forward_operator(np.array([1.0]), -np.asarray(den, float) - 1, bmag, bpsi, alt, "O", 10)
     except Exception as exc:                   # noqa: BLE001
         print("negative density ->", type(exc).__name__, exc)
+    gen_snell(lib)
     print("fixtures written to", OUT)
 
 
+def gen_snell(lib):
+    """G8: the reference's stratified Snell's-law tracer (library.py:1096-1268) on two profiles:
+    the Gaussian layer of reference test_core.py:727-730 (grid starts at the ground) and the Day
+    example profile (grid starts at 80 km: the ground level is inserted).  Ragged path arrays are
+    stored concatenated with offsets."""
+    day = load_example("Day")
+    alt_g = np.linspace(0, 600, 200)
+    gauss = {"alt": alt_g, "den": 1e12 * np.exp(-(alt_g - 250) ** 2 / (2 * 60 ** 2)),
+             "bmag": np.full_like(alt_g, 4e-5), "bpsi": np.full_like(alt_g, 45.0)}
+    g8 = {}
+    for name, prof in (("gauss", gauss), ("day", day)):
+        for k in ("alt", "den", "bmag", "bpsi"):
+            g8[f"{name}_{k}"] = prof[k]
+        rays, scal, xs, zs, offs = [], [], [], [], [0]
+        for mode_i, mode in enumerate(("O", "X")):
+            for f_mhz in (2.0, 3.5, 5.0, 7.0, 9.0, 10.0, 12.5, 16.0):
+                for elev in (5.0, 20.0, 45.0, 70.0, 85.0, 89.9, 90.0):
+                    r = lib.trace_ray_cartesian_snells(f_mhz * 1e6, elev, prof["alt"], prof["den"], prof["bmag"],
+                                                       prof["bpsi"], mode)
+                    rays.append((mode_i, f_mhz * 1e6, elev))
+                    scal.append([r[k] for k in ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint",
+                                                "ground_range_km", "x_apex_km", "z_apex_km")])
+                    x = np.atleast_1d(np.asarray(r["x"], dtype=float))
+                    z = np.atleast_1d(np.asarray(r["z"], dtype=float))
+                    if x.size == 1 and np.isnan(x[0]):
+                        x = z = np.empty(0)
+                    xs.append(x)
+                    zs.append(z)
+                    offs.append(offs[-1] + x.size)
+        g8[f"{name}_rays"] = np.array(rays)
+        g8[f"{name}_scalars"] = np.array(scal, dtype=float)
+        g8[f"{name}_x"] = np.concatenate(xs)
+        g8[f"{name}_z"] = np.concatenate(zs)
+        g8[f"{name}_offsets"] = np.array(offs)
+        print("G8", name, "rays", len(rays), "traced", int(np.isfinite(np.array(scal)[:, 0]).sum()), flush=True)
+    # helper known answers, reference test_core.py:613-635
+    g8["tan_cases"] = np.array([[2.0, 1.0], [1.0000001, 1.0], [1e-6, 1e-7]])
+    g8["tan_values"] = np.array([lib.tan_from_mu_scalar(m, p) for m, p in g8["tan_cases"]])
+    np.savez(os.path.join(OUT, "g8_snell.npz"), **g8)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["g8"]:
+        np.seterr(all="ignore")
+        gen_snell(load_reference_library())
+    else:
+        main()

@@ -67,6 +67,10 @@ _PROTOTYPES = {
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_uint32]),
+    "prhf_snell_cartesian_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
     "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -196,6 +200,12 @@ class Context:
         return self._lib.prhf_vfo_residual_f64(self._h, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt,
                                                prof_stride, alt_stride, mult, n_points, mode, vh_obs,
                                                vh or None, residual or None, cost or None, flags)
+
+    def snell_cartesian(self, freq_hz, elev, prof_idx, n_rays, den, bmag, bpsi, alt, n_prof, n_alt, alt_stride,
+                        mode, out, path_x, path_z, path_stride, flags):
+        return self._lib.prhf_snell_cartesian_f64(self._h, freq_hz, elev, prof_idx or None, n_rays, den, bmag, bpsi,
+                                                  alt, n_prof, n_alt, alt_stride, mode, out, path_x or None,
+                                                  path_z or None, path_stride, flags)
 
     def occupancy(self, n_alt, math):
         n = ctypes.c_int32(0)

@@ -562,6 +562,84 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
     return PRHF_OK;
 }
 
+int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* elevation_deg,
+                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                             int64_t alt_stride_elems, int32_t mode, double* out, double* path_x, double* path_z,
+                             int64_t path_stride, uint32_t flags) {
+    if (!c) return fail(PRHF_EINVAL, "null context");
+    if (!freq_hz || !elevation_deg || !den || !bmag || !bpsi || !alt || !out)
+        return fail(PRHF_EINVAL, "null array pointer");
+    if (n_rays < 0 || n_prof < 1 || n_alt < 2 || n_alt > 3000) return fail(PRHF_EINVAL, "bad shape");
+    if ((path_x == nullptr) != (path_z == nullptr)) return fail(PRHF_EINVAL, "path_x and path_z go together");
+    if (path_x && path_stride < 2 * (n_alt + 1) - 1)
+        return fail(PRHF_EINVAL, "path_stride must hold 2 (n_alt + 1) - 1 nodes");
+    if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "Mode must be O or X");
+    if (alt_stride_elems != 0 && alt_stride_elems != n_alt) return fail(PRHF_EINVAL, "alt stride is 0 or n_alt");
+    if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
+    if (n_rays == 0) return PRHF_OK;
+    const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    if (!dev && profile_index)
+        for (int64_t r = 0; r < n_rays; ++r)
+            if (profile_index[r] < 0 || profile_index[r] >= n_prof)
+                return fail(PRHF_EINVAL, "profile_index[%lld] outside [0, n_prof)", (long long)r);
+    HIP_TRY(hipSetDevice(c->device));
+    prhf::SnellArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_rays = n_rays; a.n_alt = n_alt; a.prof_stride = n_alt; a.alt_stride = alt_stride_elems;
+    a.path_stride = path_x ? path_stride : 0;
+    a.mode = mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
+    a.status = c->d_status;
+    const size_t prof_elems = (size_t)n_prof * (size_t)n_alt;
+    const size_t alt_elems = alt_stride_elems ? prof_elems : (size_t)n_alt;
+    const size_t path_elems = path_x ? (size_t)n_rays * (size_t)path_stride : 0;
+    if (dev) {
+        a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.freq_hz = freq_hz; a.elev_deg = elevation_deg;
+        a.prof_idx = reinterpret_cast<const long long*>(profile_index);
+        a.out = out; a.path_x = path_x; a.path_z = path_z;
+    } else {
+        const size_t elems = 3 * prof_elems + alt_elems + 3 * (size_t)n_rays + PRHF_SNELL_OUTPUTS * (size_t)n_rays +
+                             2 * path_elems;
+        int rc = ensure(c, c->arena, elems * 8);
+        if (rc != PRHF_OK) return rc;
+        double* p = static_cast<double*>(c->arena.p);
+        double* d_den = p; p += prof_elems;
+        double* d_bmag = p; p += prof_elems;
+        double* d_bpsi = p; p += prof_elems;
+        double* d_alt = p; p += alt_elems;
+        double* d_f = p; p += n_rays;
+        double* d_e = p; p += n_rays;
+        long long* d_i = reinterpret_cast<long long*>(p); p += n_rays;
+        double* d_out = p; p += PRHF_SNELL_OUTPUTS * (size_t)n_rays;
+        double* d_px = path_x ? p : nullptr; p += path_elems;
+        double* d_pz = path_x ? p : nullptr;
+        HIP_TRY(hipMemcpyAsync(d_den, den, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_bmag, bmag, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_alt, alt, alt_elems * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_f, freq_hz, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_e, elevation_deg, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        if (profile_index)
+            HIP_TRY(hipMemcpyAsync(d_i, profile_index, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.freq_hz = d_f; a.elev_deg = d_e;
+        a.prof_idx = profile_index ? d_i : nullptr;
+        a.out = d_out; a.path_x = d_px; a.path_z = d_pz;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(prhf::launch_snell_cartesian(a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    c->status_pending = true;
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(out, a.out, PRHF_SNELL_OUTPUTS * (size_t)n_rays * 8, hipMemcpyDeviceToHost, c->stream));
+        if (path_x) {
+            HIP_TRY(hipMemcpyAsync(path_x, a.path_x, path_elems * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(path_z, a.path_z, path_elems * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    return prhf_sync(c);
+}
+
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {
     if (!c || !workgroups_per_cu) return fail(PRHF_EINVAL, "null pointer");
     if (n_alt < 1 || n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt out of range");

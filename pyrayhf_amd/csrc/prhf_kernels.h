@@ -97,6 +97,25 @@ struct RegridArgs {
     int n_points, mode;
 };
 hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream);
+// Stratified Snell's-law tracer (library.py:1096-1268), one wavefront per ray; device pointers.
+#define PRHF_SNELL_OUTPUTS 8   // path km, delay s, x_mid, z_mid, ground range, x_turn, z_turn, n_path
+struct SnellArgs {
+    const double* den;
+    const double* bmag;
+    const double* bpsi;
+    const double* alt;
+    const double* freq_hz;       // (n_rays)
+    const double* elev_deg;      // (n_rays)
+    const long long* prof_idx;   // (n_rays) or null: every ray uses profile 0
+    double* out;                 // (n_rays, PRHF_SNELL_OUTPUTS)
+    double* path_x;              // (n_rays, path_stride) or null
+    double* path_z;
+    unsigned* status;
+    long long n_rays, n_alt, prof_stride, alt_stride, path_stride;
+    int mode;
+};
+hipError_t launch_snell_cartesian(const SnellArgs& a, hipStream_t stream);
+
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,
                            double* residual, double* cost, hipStream_t stream);

@@ -33,6 +33,7 @@ constexpr double kGyro = 2.799249247e10;            // library.py:64
 constexpr double kBackoff = 1e-6;                   // library.py:378
 constexpr double kDegToRad = 0.017453292519943295;  // numpy deg2rad multiplies by pi/180
 constexpr double kUnmagTol = 1e-12;                 // library.py:163
+constexpr double kLightKmS = 299792.458;            // library.py:70
 constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
 
 // One bottomside level.  u0..u3 depend on the tier and (fast tier) on the profile:
@@ -1012,6 +1013,8 @@ hipError_t launch_residual(const double* vh_model, const double* vh_obs, long lo
                        n_prof, n_freq, residual, cost);
     return hipGetLastError();
 }
+
+#include "prhf_snell.inc"
 
 // Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu) {

@@ -1,0 +1,81 @@
+"""Stratified Snell's-law tracer on the GPU against the reference's own outputs (fixture G8,
+trace_ray_cartesian_snells run by oracle/gen_golden.py) and its structural test."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["gauss", "day"])
+def test_batch_against_reference_rays(name):
+    from pyrayhf_amd import tracers
+    g = load_golden("g8_snell.npz")
+    prof = [g[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
+    rays, want, offs = g[f"{name}_rays"], g[f"{name}_scalars"], g[f"{name}_offsets"]
+    for mode_i, mode in enumerate("OX"):
+        sel = np.nonzero(rays[:, 0] == mode_i)[0]
+        r = tracers.trace_rays_cartesian_snells(rays[sel, 1], rays[sel, 2], *prof, mode, return_paths=True)
+        w = want[sel]
+        traced = np.isfinite(w[:, 0])
+        assert np.array_equal(np.isfinite(r["group_path_km"]), traced)           # same rays turn
+        assert np.all(r["n_path"][~traced] == 0)
+        np.testing.assert_allclose(r["group_path_km"][traced], w[traced, 0], rtol=1e-12)
+        np.testing.assert_allclose(r["group_delay_sec"][traced], w[traced, 1], rtol=1e-12)
+        gr = w[traced, 4]
+        np.testing.assert_allclose(r["ground_range_km"][traced][np.isfinite(gr)], gr[np.isfinite(gr)], rtol=1e-12,
+                                   atol=1e-12)
+        assert np.array_equal(np.isnan(r["ground_range_km"][traced]), np.isnan(gr))
+        for k, i in enumerate(sel):
+            n = offs[i + 1] - offs[i]
+            assert r["n_path"][k] == n
+            if n == 0:
+                continue
+            x_ref, z_ref = g[f"{name}_x"][offs[i]:offs[i + 1]], g[f"{name}_z"][offs[i]:offs[i + 1]]
+            np.testing.assert_allclose(r["x"][k, :n], x_ref, rtol=1e-12, atol=1e-10)
+            np.testing.assert_allclose(r["z"][k, :n], z_ref, rtol=1e-13, atol=1e-12)
+            assert np.all(np.isnan(r["x"][k, n:]))
+            # the reference's midpoint is the first node whose cumulative length reaches half the path: by
+            # symmetry that is the apex or, one rounding away, the node before it
+            apex = n // 2
+            assert any(abs(r["x_midpoint"][k] - x_ref[j]) <= 1e-9 * max(1.0, abs(x_ref[j])) for j in (apex - 1, apex))
+            assert any(abs(w[k, 2] - x_ref[j]) <= 1e-9 * max(1.0, abs(x_ref[j])) for j in (apex - 1, apex))
+            np.testing.assert_allclose(r["z_turn_km"][k], z_ref[apex], rtol=1e-13)
+            np.testing.assert_allclose(r["x_turn_km"][k], x_ref[apex], rtol=1e-12, atol=1e-10)
+
+
+def test_single_ray_dict_like_the_reference():
+    # reference test_core.py:724-768
+    from pyrayhf_amd import tracers
+    alt_km = np.linspace(0, 600, 200)
+    Ne = 1e12 * np.exp(-(alt_km - 250) ** 2 / (2 * 60 ** 2))
+    res = tracers.trace_ray_cartesian_snells(f0_Hz=10e6, elevation_deg=45.0, alt_km=alt_km, Ne=Ne,
+                                             Babs=np.full_like(alt_km, 4e-5), bpsi=np.full_like(alt_km, 45.0), mode="O")
+    assert {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km"} <= set(res)
+    assert np.all(np.isfinite(res["x"])) and np.all(np.isfinite(res["z"]))
+    assert res["group_path_km"] > 0 and res["group_delay_sec"] > 0 and res["ground_range_km"] > 0
+    z = res["z"]
+    assert np.isclose(z[0], 0.0, atol=1e-3) and np.nanmax(z) > 50.0 and np.isclose(z[-1], 0.0, atol=1e-2)
+    # a ray that escapes: every entry NaN
+    esc = tracers.trace_ray_cartesian_snells(30e6, 80.0, alt_km, Ne, np.full_like(alt_km, 4e-5),
+                                             np.full_like(alt_km, 45.0), "O")
+    assert all(np.all(np.isnan(v)) for v in esc.values())
+    with pytest.raises(ValueError, match="Mode must be O or X"):
+        tracers.trace_ray_cartesian_snells(10e6, 45.0, alt_km, Ne, Ne, Ne, "Q")
+
+
+def test_rays_over_several_profiles_match_single_profile_calls():
+    from pyrayhf_amd import tracers
+    g = load_golden("g5_chapman64.npz")
+    f = np.array([4e6, 6e6, 8e6, 5e6, 7e6, 3e6])
+    e = np.array([30.0, 50.0, 70.0, 80.0, 20.0, 60.0])
+    idx = np.array([0, 3, 5, 3, 1, 0])
+    many = tracers.trace_rays_cartesian_snells(f, e, g["alt"], g["den"][:6], g["bmag"][:6], g["bpsi"][:6], "X",
+                                               profile_index=idx)
+    for k in range(f.size):
+        one = tracers.trace_rays_cartesian_snells(f[k], e[k], g["alt"], g["den"][idx[k]], g["bmag"][idx[k]],
+                                                  g["bpsi"][idx[k]], "X")
+        for key in ("group_path_km", "group_delay_sec", "ground_range_km", "z_turn_km"):
+            assert np.array_equal(many[key][k:k + 1], one[key], equal_nan=True), (k, key)

@@ -113,3 +113,28 @@ def test_error_behaviour():
         orc.virtual_heights(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "Z", 10)
     with pytest.raises(ValueError, match="Density must be non-negative"):  # reference library.py:93-94
         orc.ratio_X(np.array([-1.0]), np.array([1e6]))
+
+
+def test_snell_cartesian_tracer_g8():
+    """oracle/snell_numpy.py against the reference's trace_ray_cartesian_snells (fixture G8), bit for bit:
+    scalars, path arrays, and the NaN outcome of rays that never turn."""
+    from oracle import snell_numpy as sn
+    g = load_golden("g8_snell.npz")
+    assert same_bits([sn.tangent_from_index(m, p) for m, p in g["tan_cases"]], g["tan_values"])
+    np.testing.assert_allclose(g["tan_values"][0], 1.0 / np.sqrt(3.0), rtol=1e-12)     # reference test_core.py:613-620
+    for name in ("gauss", "day"):
+        prof = [g[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
+        offs = g[f"{name}_offsets"]
+        for i, (mode_i, f_hz, elev) in enumerate(g[f"{name}_rays"]):
+            r = sn.trace_cartesian(f_hz, elev, *prof, "OX"[int(mode_i)])
+            got = [r[k] for k in ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km",
+                                  "x_apex_km", "z_apex_km")]
+            assert same_bits(got, g[f"{name}_scalars"][i]), (name, i, got, g[f"{name}_scalars"][i])
+            x = np.atleast_1d(np.asarray(r["x"], dtype=float))
+            if offs[i + 1] == offs[i]:
+                assert x.size == 1 and np.isnan(x[0])
+            else:
+                assert same_bits(x, g[f"{name}_x"][offs[i]:offs[i + 1]])
+                assert same_bits(r["z"], g[f"{name}_z"][offs[i]:offs[i + 1]])
+    traced = np.isfinite(g["gauss_scalars"][:, 0])
+    assert 20 < traced.sum() < traced.size          # both outcomes are exercised
