@@ -191,6 +191,19 @@ int prhf_snell_cartesian_f64(prhf_ctx* ctx, const double* freq_hz, const double*
                              int64_t alt_stride_elems, int32_t mode, double* out, double* path_x, double* path_z,
                              int64_t path_stride, uint32_t flags);
 
+/*
+ * The same over a spherical Earth (Bouguer's law mu r sin(theta) = const, adaptive midpoint sub-steps towards
+ * the apex).  Replaces: trace_ray_spherical_snells (reference library.py:1460-1713); the four controls are
+ * its R_E (6371 km), dz_target_km (1.0), apex_boost (200.0) and max_substeps (400).  Outputs as for the
+ * flat-Earth tracer, with x = R_E * phi.
+ */
+int prhf_snell_spherical_f64(prhf_ctx* ctx, const double* freq_hz, const double* elevation_deg,
+                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                             int64_t alt_stride_elems, int32_t mode, double earth_radius_km, double dz_target_km,
+                             double apex_boost, int32_t max_substeps, double* out, double* path_x, double* path_z,
+                             int64_t path_stride, uint32_t flags);
+
 /* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
  * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
 int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);

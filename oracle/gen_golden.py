@@ -289,6 +289,33 @@ def gen_snell(lib):
     g8["tan_values"] = np.array([lib.tan_from_mu_scalar(m, p) for m, p in g8["tan_cases"]])
     np.savez(os.path.join(OUT, "g8_snell.npz"), **g8)
 
+    # G9: the spherical-Earth tracer (library.py:1460-1713) on the same two profiles
+    g9 = {}
+    for name, prof in (("gauss", gauss), ("day", day)):
+        rays, scal, xs, zs, offs = [], [], [], [], [0]
+        for mode_i, mode in enumerate(("O", "X")):
+            for f_mhz in (2.0, 5.0, 7.0, 10.0, 12.5):
+                for elev in (5.0, 20.0, 45.0, 70.0, 89.9, 90.0):
+                    r = lib.trace_ray_spherical_snells(f_mhz * 1e6, elev, prof["alt"], prof["den"], prof["bmag"],
+                                                       prof["bpsi"], mode)
+                    rays.append((mode_i, f_mhz * 1e6, elev))
+                    scal.append([r.get(k, np.nan) for k in ("group_path_km", "group_delay_sec", "x_midpoint",
+                                                            "z_midpoint", "ground_range_km")])
+                    x = np.atleast_1d(np.asarray(r["x"], dtype=float))
+                    z = np.atleast_1d(np.asarray(r["z"], dtype=float))
+                    if x.size == 1 and np.isnan(x[0]):
+                        x = z = np.empty(0)
+                    xs.append(x)
+                    zs.append(z)
+                    offs.append(offs[-1] + x.size)
+        g9[f"{name}_rays"] = np.array(rays)
+        g9[f"{name}_scalars"] = np.array(scal, dtype=float)
+        g9[f"{name}_x"] = np.concatenate(xs)
+        g9[f"{name}_z"] = np.concatenate(zs)
+        g9[f"{name}_offsets"] = np.array(offs)
+        print("G9", name, "rays", len(rays), "traced", int(np.isfinite(np.array(scal)[:, 0]).sum()), flush=True)
+    np.savez(os.path.join(OUT, "g9_snell_spherical.npz"), **g9)
+
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["g8"]:

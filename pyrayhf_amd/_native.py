@@ -71,6 +71,11 @@ _PROTOTYPES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
         ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "prhf_snell_spherical_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
     "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -205,6 +210,13 @@ class Context:
                         mode, out, path_x, path_z, path_stride, flags):
         return self._lib.prhf_snell_cartesian_f64(self._h, freq_hz, elev, prof_idx or None, n_rays, den, bmag, bpsi,
                                                   alt, n_prof, n_alt, alt_stride, mode, out, path_x or None,
+                                                  path_z or None, path_stride, flags)
+
+    def snell_spherical(self, freq_hz, elev, prof_idx, n_rays, den, bmag, bpsi, alt, n_prof, n_alt, alt_stride,
+                        mode, r_e, dz_target, apex_boost, max_substeps, out, path_x, path_z, path_stride, flags):
+        return self._lib.prhf_snell_spherical_f64(self._h, freq_hz, elev, prof_idx or None, n_rays, den, bmag, bpsi,
+                                                  alt, n_prof, n_alt, alt_stride, mode, float(r_e), float(dz_target),
+                                                  float(apex_boost), int(max_substeps), out, path_x or None,
                                                   path_z or None, path_stride, flags)
 
     def occupancy(self, n_alt, math):

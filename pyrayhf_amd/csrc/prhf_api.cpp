@@ -562,11 +562,16 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
     return PRHF_OK;
 }
 
-int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* elevation_deg,
-                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
-                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
-                             int64_t alt_stride_elems, int32_t mode, double* out, double* path_x, double* path_z,
-                             int64_t path_stride, uint32_t flags) {
+namespace {
+struct SnellGeometry {
+    int geometry;
+    double earth_radius_km, dz_target_km, apex_boost;
+    int max_substeps;
+};
+int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, const double* elevation_deg,
+              const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+              const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt, int64_t alt_stride_elems,
+              int32_t mode, double* out, double* path_x, double* path_z, int64_t path_stride, uint32_t flags) {
     if (!c) return fail(PRHF_EINVAL, "null context");
     if (!freq_hz || !elevation_deg || !den || !bmag || !bpsi || !alt || !out)
         return fail(PRHF_EINVAL, "null array pointer");
@@ -589,6 +594,11 @@ int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* e
     a.n_rays = n_rays; a.n_alt = n_alt; a.prof_stride = n_alt; a.alt_stride = alt_stride_elems;
     a.path_stride = path_x ? path_stride : 0;
     a.mode = mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
+    a.geometry = geo.geometry;
+    a.earth_radius_km = geo.earth_radius_km;
+    a.dz_target_km = geo.dz_target_km;
+    a.apex_boost = geo.apex_boost;
+    a.max_substeps = geo.max_substeps;
     a.status = c->d_status;
     const size_t prof_elems = (size_t)n_prof * (size_t)n_alt;
     const size_t alt_elems = alt_stride_elems ? prof_elems : (size_t)n_alt;
@@ -626,7 +636,7 @@ int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* e
         a.out = d_out; a.path_x = d_px; a.path_z = d_pz;
     }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(prhf::launch_snell_cartesian(a, c->stream));
+    HIP_TRY(prhf::launch_snell(a, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     c->status_pending = true;
@@ -638,6 +648,30 @@ int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* e
         }
     }
     return prhf_sync(c);
+}
+}  // namespace
+
+int prhf_snell_cartesian_f64(prhf_ctx* c, const double* freq_hz, const double* elevation_deg,
+                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                             int64_t alt_stride_elems, int32_t mode, double* out, double* path_x, double* path_z,
+                             int64_t path_stride, uint32_t flags) {
+    const SnellGeometry geo{0, 6371.0, 1.0, 200.0, 400};
+    return snell_run(c, geo, freq_hz, elevation_deg, profile_index, n_rays, den, bmag, bpsi, alt, n_prof, n_alt,
+                     alt_stride_elems, mode, out, path_x, path_z, path_stride, flags);
+}
+
+int prhf_snell_spherical_f64(prhf_ctx* c, const double* freq_hz, const double* elevation_deg,
+                             const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
+                             const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                             int64_t alt_stride_elems, int32_t mode, double earth_radius_km, double dz_target_km,
+                             double apex_boost, int32_t max_substeps, double* out, double* path_x, double* path_z,
+                             int64_t path_stride, uint32_t flags) {
+    if (!(earth_radius_km > 0.0) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) || max_substeps < 1)
+        return fail(PRHF_EINVAL, "bad spherical tracer controls");
+    const SnellGeometry geo{1, earth_radius_km, dz_target_km, apex_boost, max_substeps};
+    return snell_run(c, geo, freq_hz, elevation_deg, profile_index, n_rays, den, bmag, bpsi, alt, n_prof, n_alt,
+                     alt_stride_elems, mode, out, path_x, path_z, path_stride, flags);
 }
 
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {

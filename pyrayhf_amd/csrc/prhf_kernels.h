@@ -113,8 +113,13 @@ struct SnellArgs {
     unsigned* status;
     long long n_rays, n_alt, prof_stride, alt_stride, path_stride;
     int mode;
+    int geometry;                // 0 flat Earth, 1 spherical Earth
+    double earth_radius_km;      // spherical only (library.py:1473, :1552-1553)
+    double dz_target_km;         // spherical sub-step controls (library.py:1470-1472)
+    double apex_boost;
+    int max_substeps;
 };
-hipError_t launch_snell_cartesian(const SnellArgs& a, hipStream_t stream);
+hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);
 
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,

@@ -1,7 +1,8 @@
 """Stratified Snell's-law ray tracing on the GPU.
 
-``trace_ray_cartesian_snells`` keeps the reference's signature and result dictionary
-(reference ``PyRayHF/library.py:1096-1268``); ``trace_rays_cartesian_snells`` traces a batch of
+``trace_ray_cartesian_snells`` and ``trace_ray_spherical_snells`` keep the reference's signatures
+and result dictionaries (reference ``PyRayHF/library.py:1096-1268``, ``:1460-1713``);
+``trace_rays_cartesian_snells`` / ``trace_rays_spherical_snells`` trace a batch of
 (frequency, elevation[, profile]) rays in one launch, one wavefront per ray.
 """
 
@@ -10,24 +11,18 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from .library import _as_rows
+from .library import _as_rows, constants
 
-__all__ = ["trace_ray_cartesian_snells", "trace_rays_cartesian_snells"]
+__all__ = ["trace_ray_cartesian_snells", "trace_rays_cartesian_snells", "trace_ray_spherical_snells",
+           "trace_rays_spherical_snells"]
 
 _KEYS = ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km", "x_turn_km",
          "z_turn_km", "n_path")
+_DICT_KEYS = ("x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km")
 
 
-def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, profile_index=None,
-                                return_paths=False, device=None):
-    """Trace ``R`` rays; ``f0_Hz`` and ``elevation_deg`` broadcast to ``(R,)``.
-
-    ``Ne, Babs, bpsi`` are ``(N_alt,)`` or ``(P, N_alt)`` with ``profile_index`` ``(R,)`` choosing the
-    column of each ray; ``alt_km`` ``(N_alt,)`` or ``(P, N_alt)``.  Returns a dict of ``(R,)`` arrays:
-    the reference's ``group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km`` plus the
-    turning point ``x_turn_km, z_turn_km`` and ``n_path``; NaN for rays that never turn.  With
-    ``return_paths`` also ``x`` and ``z``: ``(R, 2 N_alt + 1)`` padded with NaN.
-    """
+def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths, device,
+                controls=None):
     if mode not in ("O", "X"):
         raise ValueError("Mode must be O or X")                     # find_mu_mup, reference library.py:225-226
     f, e = np.broadcast_arrays(np.asarray(f0_Hz, dtype=np.float64), np.asarray(elevation_deg, dtype=np.float64))
@@ -50,17 +45,53 @@ def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mo
     px = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
     pz = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
     ctx = _native.context(device)
-    rc = ctx.snell_cartesian(f.ctypes.data, e.ctypes.data, idx.ctypes.data if idx is not None else None, f.size,
-                             d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof, n_alt,
-                             n_alt if a.ndim == 2 else 0, _native.MODE_O if mode == "O" else _native.MODE_X,
-                             out.ctypes.data, px.ctypes.data if return_paths else None,
-                             pz.ctypes.data if return_paths else None, stride, 0)
+    common = (f.ctypes.data, e.ctypes.data, idx.ctypes.data if idx is not None else None, f.size, d2.ctypes.data,
+              b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof, n_alt, n_alt if a.ndim == 2 else 0,
+              _native.MODE_O if mode == "O" else _native.MODE_X)
+    tail = (out.ctypes.data, px.ctypes.data if return_paths else None, pz.ctypes.data if return_paths else None,
+            stride, 0)
+    rc = ctx.snell_spherical(*common, *controls, *tail) if spherical else ctx.snell_cartesian(*common, *tail)
     _native.raise_for(rc)
     res = {k: out[:, i].copy() for i, k in enumerate(_KEYS)}
     res["n_path"] = res["n_path"].astype(np.int64)
     if return_paths:
         res["x"], res["z"] = px, pz
     return res
+
+
+def _single(r, apex_keys):
+    n = int(r["n_path"][0])
+    if n == 0:
+        return {k: np.nan for k in _DICT_KEYS + (("x_apex_km", "z_apex_km") if apex_keys else ())}
+    return {"x": r["x"][0, :n].copy(), "z": r["z"][0, :n].copy(),
+            "group_path_km": float(r["group_path_km"][0]), "group_delay_sec": float(r["group_delay_sec"][0]),
+            "x_midpoint": float(r["x_midpoint"][0]), "z_midpoint": float(r["z_midpoint"][0]),
+            "ground_range_km": float(r["ground_range_km"][0]),
+            "x_apex_km": float(r["x_midpoint"][0]), "z_apex_km": float(r["z_midpoint"][0])}
+
+
+def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, profile_index=None,
+                                return_paths=False, device=None):
+    """Trace ``R`` rays over a flat Earth; ``f0_Hz`` and ``elevation_deg`` broadcast to ``(R,)``.
+
+    ``Ne, Babs, bpsi`` are ``(N_alt,)`` or ``(P, N_alt)`` with ``profile_index`` ``(R,)`` choosing the
+    column of each ray; ``alt_km`` ``(N_alt,)`` or ``(P, N_alt)``.  Returns a dict of ``(R,)`` arrays:
+    the reference's ``group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km`` plus the
+    turning point ``x_turn_km, z_turn_km`` and ``n_path``; NaN for rays that never turn.  With
+    ``return_paths`` also ``x`` and ``z``: ``(R, 2 N_alt + 1)`` padded with NaN.
+    """
+    return _trace_rays(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths,
+                       device)
+
+
+def trace_rays_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
+                                apex_boost=200.0, max_substeps=400, R_E=None, profile_index=None,
+                                return_paths=False, device=None):
+    """The same over a spherical Earth (Bouguer's law), with the reference's apex-refinement controls
+    (library.py:1470-1473); ``x`` is the ground distance ``R_E * phi``."""
+    r_e = constants()[2] if R_E is None else float(R_E)
+    return _trace_rays(True, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths, device,
+                       controls=(r_e, dz_target_km, apex_boost, max_substeps))
 
 
 def trace_ray_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, device=None):
@@ -70,12 +101,14 @@ def trace_ray_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mod
     never turns returns NaN for every entry."""
     r = trace_rays_cartesian_snells(np.float64(f0_Hz), np.float64(elevation_deg), alt_km, Ne, Babs, bpsi, mode,
                                     return_paths=True, device=device)
-    n = int(r["n_path"][0])
-    if n == 0:
-        return {k: np.nan for k in ("x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint",
-                                    "ground_range_km", "x_apex_km", "z_apex_km")}
-    return {"x": r["x"][0, :n].copy(), "z": r["z"][0, :n].copy(),
-            "group_path_km": float(r["group_path_km"][0]), "group_delay_sec": float(r["group_delay_sec"][0]),
-            "x_midpoint": float(r["x_midpoint"][0]), "z_midpoint": float(r["z_midpoint"][0]),
-            "ground_range_km": float(r["ground_range_km"][0]),
-            "x_apex_km": float(r["x_midpoint"][0]), "z_apex_km": float(r["z_midpoint"][0])}
+    return _single(r, apex_keys=True)
+
+
+def trace_ray_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
+                               apex_boost=200.0, max_substeps=400, R_E=None, device=None):
+    """One ray over a spherical Earth; the reference's signature and result dict (library.py:1460-1713).
+    A ray that never turns returns the reference's seven-key NaN dict (library.py:1577-1583)."""
+    r = trace_rays_spherical_snells(np.float64(f0_Hz), np.float64(elevation_deg), alt_km, Ne, Babs, bpsi, mode,
+                                    dz_target_km=dz_target_km, apex_boost=apex_boost, max_substeps=max_substeps,
+                                    R_E=R_E, return_paths=True, device=device)
+    return _single(r, apex_keys=False)

@@ -79,3 +79,49 @@ def test_rays_over_several_profiles_match_single_profile_calls():
                                                   g["bpsi"][idx[k]], "X")
         for key in ("group_path_km", "group_delay_sec", "ground_range_km", "z_turn_km"):
             assert np.array_equal(many[key][k:k + 1], one[key], equal_nan=True), (k, key)
+
+
+@pytest.mark.parametrize("name", ["gauss", "day"])
+def test_spherical_batch_against_reference_rays(name):
+    """trace_ray_spherical_snells (reference library.py:1460-1713) run by oracle/gen_golden.py: fixture G9."""
+    from pyrayhf_amd import tracers
+    g = load_golden("g9_snell_spherical.npz")
+    p = load_golden("g8_snell.npz")
+    prof = [p[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
+    rays, want, offs = g[f"{name}_rays"], g[f"{name}_scalars"], g[f"{name}_offsets"]
+    for mode_i, mode in enumerate("OX"):
+        sel = np.nonzero(rays[:, 0] == mode_i)[0]
+        r = tracers.trace_rays_spherical_snells(rays[sel, 1], rays[sel, 2], *prof, mode, return_paths=True)
+        w = want[sel]
+        traced = np.isfinite(w[:, 0])
+        assert np.array_equal(np.isfinite(r["group_path_km"]), traced)
+        np.testing.assert_allclose(r["group_path_km"][traced], w[traced, 0], rtol=1e-11)
+        np.testing.assert_allclose(r["group_delay_sec"][traced], w[traced, 1], rtol=1e-11)
+        gr = w[traced, 4]
+        fin = np.isfinite(gr)
+        np.testing.assert_allclose(r["ground_range_km"][traced][fin], gr[fin], rtol=1e-11, atol=1e-10)
+        for k, i in enumerate(sel):
+            n = offs[i + 1] - offs[i]
+            assert r["n_path"][k] == n
+            if n:
+                np.testing.assert_allclose(r["x"][k, :n], g[f"{name}_x"][offs[i]:offs[i + 1]], rtol=1e-11, atol=1e-9)
+                np.testing.assert_allclose(r["z"][k, :n], g[f"{name}_z"][offs[i]:offs[i + 1]], rtol=1e-13, atol=1e-12)
+
+
+def test_spherical_single_ray_and_flat_limit():
+    """Structure of the reference's dict, and its flat-Earth limit test (reference test_core.py:843-887):
+    with a huge Earth radius the spherical tracer approaches the flat-Earth one."""
+    from pyrayhf_amd import tracers
+    alt_km = np.linspace(0, 600, 200)
+    Ne = 1e12 * np.exp(-(alt_km - 250) ** 2 / (2 * 60 ** 2))
+    B, psi = np.full_like(alt_km, 4e-5), np.full_like(alt_km, 45.0)
+    sph = tracers.trace_ray_spherical_snells(10e6, 45.0, alt_km, Ne, B, psi, "O")
+    assert np.all(np.isfinite(sph["x"])) and sph["group_path_km"] > 0 and sph["ground_range_km"] > 0
+    assert np.isclose(sph["z"][0], 0.0, atol=1e-3) and np.isclose(sph["z"][-1], 0.0, atol=1e-3)
+    flat = tracers.trace_ray_cartesian_snells(10e6, 45.0, alt_km, Ne, B, psi, "O")
+    big = tracers.trace_ray_spherical_snells(10e6, 45.0, alt_km, Ne, B, psi, "O", R_E=1e9)
+    assert abs(big["ground_range_km"] - flat["ground_range_km"]) <= 0.03 * flat["ground_range_km"]
+    assert abs(big["group_path_km"] - flat["group_path_km"]) <= 0.03 * flat["group_path_km"]
+    esc = tracers.trace_ray_spherical_snells(30e6, 80.0, alt_km, Ne, B, psi, "O")
+    assert set(esc) == {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km"}
+    assert all(np.isnan(v) for v in esc.values())

@@ -138,3 +138,23 @@ def test_snell_cartesian_tracer_g8():
                 assert same_bits(r["z"], g[f"{name}_z"][offs[i]:offs[i + 1]])
     traced = np.isfinite(g["gauss_scalars"][:, 0])
     assert 20 < traced.sum() < traced.size          # both outcomes are exercised
+
+
+def test_snell_spherical_tracer_g9():
+    """oracle/snell_numpy.py trace_spherical against the reference's trace_ray_spherical_snells (fixture G9)."""
+    from oracle import snell_numpy as sn
+    g = load_golden("g9_snell_spherical.npz")
+    p = load_golden("g8_snell.npz")
+    for name in ("gauss", "day"):
+        prof = [p[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
+        offs = g[f"{name}_offsets"]
+        for i, (mode_i, f_hz, elev) in enumerate(g[f"{name}_rays"]):
+            r = sn.trace_spherical(f_hz, elev, *prof, "OX"[int(mode_i)])
+            got = [r[k] for k in ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km")]
+            assert same_bits(got, g[f"{name}_scalars"][i]), (name, i, got, g[f"{name}_scalars"][i])
+            if offs[i + 1] > offs[i]:
+                assert same_bits(r["x"], g[f"{name}_x"][offs[i]:offs[i + 1]])
+                assert same_bits(r["z"], g[f"{name}_z"][offs[i]:offs[i + 1]])
+            else:
+                assert np.isnan(r["x"]) and set(r) == {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint",
+                                                        "z_midpoint", "ground_range_km"}      # library.py:1577-1583
