@@ -168,8 +168,20 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq);
+        out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
+    }
+    // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup
+    // the lowest indices so that a mixed launch does not end on its longest workgroups.
+    std::stable_sort(a.seg, a.seg + n_segs, [](const prhf::SegDev& x, const prhf::SegDev& y) {
+        auto cost = [](const prhf::SegDev& s) {
+            return (double)s.n_points / s.chunks / s.blocks_per_prof * (s.tier == 0 ? 3.5 : 1.0);
+        };
+        return cost(x) > cost(y);
+    });
+    for (int i = 0; i < n_segs; ++i) {
+        prhf::SegDev& s = a.seg[i];
+        const long long P = s.prof_end - s.prof_begin;
         s.block_begin = blocks;
-        const long long P = u.prof_end - u.prof_begin;
         blocks += P * s.blocks_per_prof;
         if (s.chunks > 1) {
             s.partial_off = partial_elems;
@@ -177,7 +189,6 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             partial_elems += P * n_freq * s.chunks;
             altmin_elems += P;
         }
-        out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + P);
     }
     if (blocks > 0x7fffffffLL) return fail(PRHF_EINVAL, "launch too large");
 

@@ -140,6 +140,7 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 //   mu^2 = N/D with N = D - X(1-X)                                                    (:232)
 //   1/(2 mu D) = sign(D) / (2 sqrt(N D))  -> one rsqrt gives mu, 1/D and that factor
 //   Y dD/dY = -2h +- (beta + h^2/beta)      (from :244-247, using Y d(alpha)/dY = 4h^2 + 2 YL^2 (1-X)^2)
+//   t = YL^2 (1-X), so alpha = h^2 + t (1-X) and dD/dX = -1 -+ t/beta                (:241-242)
 //   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
 // YL^2 = Y2 - Y2 S2 (absolute error 1e-16 Y2: harmless, YL^2 only enters through alpha and t).
 // index_fast_core leaves the mu > 1 cliff (:238) to the caller: *rad_out = fl(1 - q).  In vacuum
@@ -169,10 +170,11 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double mu = __builtin_fabs(Nw);
     const double rD = Nw * w;
     const double q = XXm1 * rD;
-    const double dDdX = -sgn * (t * rbeta) - 1.0;              // :241-242
-    const double YdDdY = sgn * (h2 * rbeta + beta) - 2.0 * h;
+    // bracket = 2X (2X - 1 + q dD/dX) + q Y dD/dY with dD/dX = -1 -+ t/beta (:241-242) and
+    // Y dD/dY = -2h +- (beta + h^2/beta), collected as 2X(2X - 1) + q [+-(beta + (h^2 - 2X t)/beta) - 2 (X + h)]
     const double two_X = X + X;
-    const double bracket = two_X * ((two_X - 1.0) + q * dDdX) + q * YdDdY;
+    const double inner = sgn * ((h2 - two_X * t) * rbeta + beta) - 2.0 * (X + h);
+    const double bracket = q * inner + (two_X * two_X - two_X);
     const double A = __builtin_copysign(0.5 * w, D);
     *mu_out = mu;
     *mup_out = mu - A * bracket;
