@@ -85,3 +85,36 @@ def test_argument_errors_are_reported_without_a_gpu():
         assert rc in (_native.EHIP, _native.EINVAL) and not h.value
         assert lib.prhf_last_error()
     assert lib.prhf_ctx_destroy(None) == _native.OK
+
+
+def test_shape_and_argument_validation_happens_on_the_host():
+    """Bad shapes are rejected before any device is touched (so also without a GPU)."""
+    g = load_golden("g1_basic.npz")
+    with pytest.raises(ValueError):
+        library.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    with pytest.raises(ValueError):
+        library.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"][:2], "O", 10)
+    with pytest.raises(ValueError):
+        library.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 0)
+    with pytest.raises(ValueError):
+        library.vertical_forward_operator(g["freq"].reshape(1, -1, 1), g["den"], g["bmag"], g["bpsi"], g["alt"])
+    with pytest.raises(ValueError, match="Mode must be O or X"):
+        library.find_mu_mup(np.ones(3), np.ones(3), np.ones(3), "Q")
+    with pytest.raises(ValueError, match="mode must be 'O' or 'X'"):
+        library.regrid_to_nonuniform_grid(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], mode="Q")
+
+
+def test_missing_library_is_a_loud_error(tmp_path, monkeypatch):
+    """A missing libprhf.so must raise, never fall back (checked in a fresh interpreter)."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from pyrayhf_amd import library, _native\n"
+            "try:\n"
+            "    library.vertical_forward_operator(np.array([1.0, 2.0]), np.array([0, 5e11, 1e12]), np.full(3, 5e-5),\n"
+            "                                      np.full(3, 60.0), np.array([100.0, 200.0, 300.0]))\n"
+            "except _native.NativeLibraryError as exc:\n"
+            "    print('LOUD', 'not found' in str(exc))\n" % REPO)
+    env = dict(os.environ, PRHF_LIB=str(tmp_path / "nowhere" / "libprhf.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "LOUD True" in out.stdout, out.stdout + out.stderr
