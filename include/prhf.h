@@ -74,9 +74,10 @@ int prhf_device_count(int* n);
 int prhf_ctx_create(int device, prhf_ctx** out);
 int prhf_ctx_destroy(prhf_ctx* ctx);
 
-/* Borrow a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own.
- * Pass NULL to return to the context's stream. */
-int prhf_ctx_set_stream(prhf_ctx* ctx, void* hip_stream);
+/* borrow != 0: launch on the caller's hipStream_t (e.g. torch's current stream; a NULL handle is the legacy
+ * default stream, which is what torch reports for its default stream).  borrow == 0: return to the context's
+ * own non-blocking stream (hip_stream is ignored). */
+int prhf_ctx_set_stream(prhf_ctx* ctx, void* hip_stream, int32_t borrow);
 
 /* Select the arithmetic tier (PRHF_MATH_*), default PRHF_MATH_AUTO. */
 int prhf_ctx_set_math(prhf_ctx* ctx, int level);

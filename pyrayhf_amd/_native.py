@@ -41,7 +41,7 @@ _PROTOTYPES = {
     "prhf_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "prhf_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "prhf_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
-    "prhf_ctx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "prhf_ctx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "prhf_ctx_set_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "prhf_vfo_batch_f64": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -98,6 +98,14 @@ def load():
             raise NativeLibraryError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C pyrayhf_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime.  If libprhf.so pulled in the system runtime first, a
+        # later `import torch` would bring a second runtime into the process and that one finds no GPU
+        # ("No HIP GPUs are available").  Loading torch first makes both share torch's runtime.
+        if os.environ.get("PRHF_NO_TORCH_PRELOAD", "") == "":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         try:
             lib = ctypes.CDLL(LIB_PATH)
         except OSError as exc:
@@ -166,8 +174,10 @@ class Context:
         except Exception:      # noqa: BLE001 - interpreter shutdown
             pass
 
-    def set_stream(self, stream_ptr):
-        raise_for(self._lib.prhf_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+    def set_stream(self, stream_ptr, borrow=True):
+        """Launch on the caller's stream (``stream_ptr`` 0 = the legacy default stream) or, with
+        ``borrow=False``, on the context's own stream."""
+        raise_for(self._lib.prhf_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None), 1 if borrow else 0))
 
     def set_math(self, level):
         raise_for(self._lib.prhf_ctx_set_math(self._h, int(level)))

@@ -345,9 +345,10 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     return PRHF_OK;
 }
 
-int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream) {
+int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream, int32_t borrow) {
     if (!c) return fail(PRHF_EINVAL, "null context");
-    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    // a borrowed NULL is the legacy default stream (what torch reports for its default stream)
+    hipStream_t next = borrow ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     if (next == c->stream) return PRHF_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));   // scratch buffers are reused across launches

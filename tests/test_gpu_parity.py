@@ -226,3 +226,24 @@ def test_torch_device_resident_inputs(lib):
     assert out.is_cuda and out.shape == (64, g["freq"].size)
     host = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000)
     assert np.array_equal(out.cpu().numpy(), host, equal_nan=True)
+
+
+def test_torch_async_launch_is_ordered_on_the_callers_stream(lib):
+    """sync=False enqueues on torch's current stream (default or side stream): a torch op issued right
+    after the call must see the finished result without any host synchronisation in between."""
+    import torch
+    g = load_golden("g5_chapman64.npz")
+    dev = torch.device("cuda:0")
+    t = {k: torch.as_tensor(g[k], device=dev) for k in ("freq", "den", "bmag", "bpsi", "alt")}
+    want = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 20000)
+    for stream in (torch.cuda.current_stream(dev), torch.cuda.Stream(dev)):
+        with torch.cuda.stream(stream):
+            out = torch.full((64, g["freq"].size), -1.0, dtype=torch.float64, device=dev)
+            lib.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", 20000,
+                                          sync=False, out=out)
+            doubled = out * 2.0                        # same stream: must run after the kernel
+        stream.synchronize()
+        assert np.array_equal(doubled.cpu().numpy(), want * 2.0, equal_nan=True)
+    # back to host inputs on the same context afterwards
+    again = lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"][:2], g["bpsi"][:2], g["alt"], "X", 20000)
+    assert_x_mode(again, want[:2], tol=1e-12)         # two profiles are chunked: another summation order
