@@ -15,6 +15,9 @@
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
 #endif
+#ifndef PRHF_LEAN_UNROLL
+#define PRHF_LEAN_UNROLL 2          // wave-iterations per trip of the fast tier's main loop
+#endif
 #define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
 #define PRHF_RED_DOUBLES 128        // block-reduction scratch (8 rows x up to 16 waves)

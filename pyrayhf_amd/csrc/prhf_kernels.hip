@@ -567,6 +567,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             asm volatile("" : "+v"(a0v));
             const double* pm = mult + lane;
             double m0 = pm[first], m1 = pm[first + 1];
+#if PRHF_LEAN_UNROLL == 2
             // two wave-iterations per trip so that the prefetch registers swap roles without moves
             for (; first + 192 <= full_end; first += 128) {
                 const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
@@ -579,6 +580,14 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                 acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
                 first += 64;
             }
+#else
+            for (; first + 128 <= full_end; first += 64) {
+                const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
+                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
+                m0 = n0;
+                m1 = n1;
+            }
+#endif
         }
     }
     int i = first + lane;
