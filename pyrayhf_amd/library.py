@@ -297,9 +297,12 @@ def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, dev
     """Several (profile range, mode, n_points) slices in ONE launch (BASELINE config 5).
 
     ``segments`` is a sequence of ``(prof_begin, prof_end, mode, n_points)``; profile ranges
-    index the rows of the 2-D inputs.  Returns ``(P, F)`` float64 (host inputs only); rows not
-    covered by any segment are NaN.
+    index the rows of the 2-D inputs.  Returns ``(P, F)`` float64; rows not covered by any segment
+    are NaN.  GPU-resident torch tensors are used in place (zero copy, launched on torch's current
+    stream, synchronised before returning) and give a tensor on the same device.
     """
+    if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):
+        return _torch_mixed(freq, den, bmag, bpsi, alt, segments, math)
     f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
     d2, b2, p2 = (np.atleast_2d(_as_rows(n, x)) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi)))
     a = _as_rows("alt", alt)
@@ -329,6 +332,45 @@ def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, dev
     for s in segs:
         covered[s.prof_begin:s.prof_end] = True
     out[~covered] = np.nan
+    return out
+
+
+def _torch_mixed(freq, den, bmag, bpsi, alt, segments, math, sync=True):
+    import torch
+
+    dev = den.device
+
+    def prep(x):
+        if not _is_torch(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev)
+        return x.to(device=dev, dtype=torch.float64).contiguous()
+
+    f = prep(freq).reshape(-1)
+    d2, b2, p2, a = prep(den), prep(bmag), prep(bpsi), prep(alt)
+    if d2.dim() != 2 or not (d2.shape == b2.shape == p2.shape):
+        raise ValueError("den, bmag and bpsi must share a (P, N_alt) shape")
+    n_prof, n_alt = d2.shape
+    if a.shape[-1] != n_alt or (a.dim() == 2 and a.shape[0] != n_prof):
+        raise ValueError("alt must have one value per density level")
+    segs, grids, off = [], [], 0
+    for (p0, p1, mode, n_points) in segments:
+        m = _multiplier(n_points)
+        segs.append(_native.Segment(int(p0), int(p1), _mode_code(mode), int(n_points), off, int(p0) * f.numel()))
+        grids.append(m)
+        off += m.size
+    out = torch.full((n_prof, f.numel()), float("nan"), dtype=torch.float64, device=dev)
+    if not segs:
+        return out
+    mult = torch.as_tensor(np.concatenate(grids), device=dev)
+    ctx = _native.context(dev.index if dev.index is not None else torch.cuda.current_device())
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_math(_default_math(None, math))
+    rc = ctx.vfo_worklist(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
+                          n_prof, n_alt, n_alt, n_alt if a.dim() == 2 else 0, mult.data_ptr(), mult.numel(), segs,
+                          out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC)
+    _native.raise_for(rc)
+    if sync:
+        _native.raise_for(ctx.sync())          # also keeps `mult` alive until the kernel has read it
     return out
 
 

@@ -247,3 +247,16 @@ def test_torch_async_launch_is_ordered_on_the_callers_stream(lib):
     # back to host inputs on the same context afterwards
     again = lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"][:2], g["bpsi"][:2], g["alt"], "X", 20000)
     assert_x_mode(again, want[:2], tol=1e-12)         # two profiles are chunked: another summation order
+
+
+def test_mixed_worklist_on_device_tensors(lib):
+    import torch
+    g = load_golden("g5_chapman64.npz")
+    segs = [(0, 8, "O", 200), (8, 14, "X", 2000), (20, 24, "X", 20000)]          # rows 14..19 uncovered
+    host = lib.vertical_forward_operator_mixed(g["freq"], g["den"][:24], g["bmag"][:24], g["bpsi"][:24], g["alt"], segs)
+    dev = torch.device("cuda:0")
+    t = [torch.as_tensor(x, device=dev) for x in (g["freq"], g["den"][:24], g["bmag"][:24], g["bpsi"][:24], g["alt"])]
+    out = lib.vertical_forward_operator_mixed(*t, segs)
+    assert out.is_cuda and out.shape == (24, g["freq"].size)
+    assert np.array_equal(out.cpu().numpy(), host, equal_nan=True)
+    assert np.all(np.isnan(host[14:20]))

