@@ -196,14 +196,19 @@ def main():
             "workgroups_per_cu": ctx.occupancy(alt.size, _native.MATH_FAST if mode == "X" and math is None
                                                else (math or _native.MATH_FAITHFUL)),
             "kernel_ms": k_ms,
-            "roofline": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # the FP64 vector ALU (not MFMA, not HBM) binds this path, so the primary
+            # roofline object prices the nominal 68 flop/point against the 78.6 TFLOP/s vector peak;
+            # the compulsory-bytes view (arithmetic intensity ~1e4 flop/B) rides along as roofline_hbm.
+            "roofline": {"bound": "fp64_valu", "achieved": aflops / (k_ms * 1e-3) / 1e12,
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": aflops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "note": "compulsory bytes only; the fused kernel is FP64-VALU bound, see roofline_valu"},
-            "roofline_valu": {"bound": "fp64_valu", "achieved": aflops / (k_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": aflops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                              "flops_per_point": FLOPS_PER_POINT},
+                         "flops_per_point": FLOPS_PER_POINT,
+                         "note": "non-MFMA FP64 vector roofline (SURVEY 8d); traffic = measured HBM bytes/launch"},
+            "roofline_hbm": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": traffic, "algorithmic_bytes": abytes,
+                             "note": "compulsory bytes only; the fused kernel is not HBM bound by construction"},
         }
 
         if world == 1 and not args.no_single_profile:

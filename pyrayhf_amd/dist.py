@@ -61,3 +61,63 @@ def gather_rows(local, n_total, group=None):
     if all(c == biggest for c in counts):
         return buf
     return torch.cat([buf[r * biggest: r * biggest + counts[r]] for r in range(world)], dim=0)
+
+
+def shard_segments(segments, world_size, rank):
+    """Cost-balanced cut of a mixed work list (BASELINE config 5).
+
+    The cost of a slice is proportional to its row count times ``n_points`` (times the reflecting
+    fraction, which the synthetic and PyIRI ensembles spread evenly over rows), so giving every rank
+    the ``shard_bounds`` block of EVERY segment gives every rank the same mix of cheap and
+    expensive rows and lets all GPUs finish together - no rank ends up with only the
+    ``n_points = 20000`` rows.
+
+    ``segments``: sequence of ``(prof_begin, prof_end, mode, n_points)`` over the global rows.
+    Returns ``(rows, local_segments)``: ``rows`` is the int64 array of global row numbers this rank
+    evaluates, in local order, and ``local_segments`` the same slices re-based onto that local
+    stack (ready for ``library.vertical_forward_operator_mixed``).  Empty cuts are dropped.
+    """
+    import numpy as np
+
+    rows, local, off = [], [], 0
+    for (p0, p1, mode, n_points) in segments:
+        lo, hi = shard_bounds(int(p1) - int(p0), world_size, rank)
+        if hi > lo:
+            rows.append(np.arange(int(p0) + lo, int(p0) + hi, dtype=np.int64))
+            local.append((off, off + hi - lo, mode, int(n_points)))
+            off += hi - lo
+    return (np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)), local
+
+
+def gather_mixed(local, segments, n_total, group=None):
+    """Reassemble the ``(n_total, F)`` result of a mixed work list cut by ``shard_segments``.
+
+    ``local`` holds this rank's rows in ``shard_segments`` order.  One padded all-gather, then each
+    rank's rows go back to their global positions; rows no segment covers stay NaN.
+    """
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cuts = [shard_segments(segments, world, r)[0] for r in range(world)]
+    if local.shape[0] != cuts[rank].size:
+        raise ValueError("local rows do not match shard_segments for this rank")
+    full = torch.full((int(n_total), local.shape[1]), float("nan"), dtype=local.dtype, device=local.device)
+    if world == 1:
+        full[torch.as_tensor(cuts[0], device=local.device)] = local
+        return full
+    biggest = max(max(c.size for c in cuts), 1)
+    send = torch.full((biggest, local.shape[1]), float("nan"), dtype=local.dtype, device=local.device)
+    send[: local.shape[0]] = local
+    device = local.device
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        send = send.cpu()
+    buf = torch.empty((world * biggest, local.shape[1]), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    buf = buf.to(device)
+    for r, rows in enumerate(cuts):
+        if rows.size:
+            full[torch.as_tensor(rows, device=device)] = buf[r * biggest: r * biggest + rows.size]
+    return full

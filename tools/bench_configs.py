@@ -42,11 +42,12 @@ alt, den, bmag, bpsi = synth.chapman_profiles(100000, 20260004, rows=slice(0, 12
 run("4 shard: 12500 Chapman x 256, X/20000", synth.sounder_frequencies(4), alt, den, bmag, bpsi, "X", 20000, reps=3)
 run("4 shard (faithful): 12500 Chapman x 256, X/20000", synth.sounder_frequencies(4), alt, den, bmag, bpsi, "X", 20000,
     reps=2, math=library.MATH_FAITHFUL)
-# config 5, per-GPU shard (1/8 of each slice): host inputs, one launch
-alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=slice(0, 50000, 8))
+# config 5, per-GPU shard: rank 0 of 8 takes its block of every slice (dist.shard_segments), one launch
+from pyrayhf_amd import dist as pdist
+CONFIG5 = [(0, 20000, "O", 200), (20000, 35000, "X", 2000), (35000, 45000, "O", 2000), (45000, 50000, "X", 20000)]
+rows, segs = pdist.shard_segments(CONFIG5, 8, 0)
+alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=rows)
 P = den.shape[0]
-cuts = [0, int(P * 0.4), int(P * 0.7), int(P * 0.9), P]
-segs = [(cuts[0], cuts[1], "O", 200), (cuts[1], cuts[2], "X", 2000), (cuts[2], cuts[3], "O", 2000), (cuts[3], cuts[4], "X", 20000)]
 f512 = synth.sounder_frequencies(5)
 tt = [torch.as_tensor(x, device=dev) for x in (f512, den, bmag, bpsi, alt)]
 for r in range(4):
