@@ -46,6 +46,9 @@ extern "C" {
 /* flags of prhf_vfo_batch_f64 / prhf_vfo_worklist_f64 */
 #define PRHF_FLAG_DEVICE_PTRS 0x1u  /* every array pointer (inputs, multiplier, output) is device memory */
 #define PRHF_FLAG_ASYNC       0x2u  /* device pointers only: enqueue and return; data errors surface at prhf_sync */
+#define PRHF_FLAG_GRID_STABLE 0x4u  /* device pointers only: the multiplier array at this address keeps its contents
+                                     * for as long as the context lives, so the table the library derives from it
+                                     * (grid steps, one small kernel) is built once per (address, length) and reused */
 
 /* arithmetic tiers, prhf_ctx_set_math (see DESIGN.md "Arithmetic tiers") */
 #define PRHF_MATH_FAITHFUL 0  /* reference operation order, IEEE divide/sqrt, no contraction */

@@ -38,6 +38,8 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
+double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
+int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
 constexpr long long kMaxAlt = 1600;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
@@ -55,9 +57,13 @@ struct prhf_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int math = PRHF_MATH_AUTO;
+    int cu_count = 256;
     DevBuf arena;     // staged host inputs + output
     DevBuf partial;   // chunk sums
     DevBuf altmin;    // per-profile min(alt) for chunked slices
+    DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
+    const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
+    int64_t pairs_len = 0;
     unsigned* d_status = nullptr;
     unsigned* h_status = nullptr;   // pinned
     unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
@@ -86,7 +92,7 @@ int ensure(prhf_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 // Decompose one slice into wave-sized items and blocks ("Launch geometry").
-void plan_slice(prhf::SegDev& s, long long n_freq) {
+void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     const long long P = s.prof_end - s.prof_begin;
     const long long pairs = P * n_freq;
     const long long N = s.n_points;
@@ -102,6 +108,17 @@ void plan_slice(prhf::SegDev& s, long long n_freq) {
     long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
                                                                  std::max<long long>(P, 1)));
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    // A long slice of one-workgroup profiles ends on whole workgroups (milliseconds each at n_points = 20000)
+    // while most of the chip has already drained.  Cut the profiles of the last kTailRounds rounds of
+    // workgroup slots into kTailBpp workgroups each: the launch then drains in a fraction of a workgroup time.
+    s.tail_prof = P;
+    s.tail_bpp = s.blocks_per_prof;
+    const long long tail = (long long)(kTailRounds * (double)wg_slots);
+    if (kTailBpp > 1 && s.blocks_per_prof == 1 && chunks == 1 && N >= 1024 && P >= 4 * tail && tail > 0 &&
+        n_freq >= (long long)kTailBpp * kWavesPerBlock) {
+        s.tail_prof = P - tail;
+        s.tail_bpp = kTailBpp;
+    }
 }
 
 // Optional second stage of a launch: residual rows against one observed trace (prhf_vfo_residual_f64).
@@ -135,9 +152,11 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         return fail(PRHF_EINVAL, "row stride shorter than a row");
     if (n_segs < 1 || n_segs > PRHF_MAX_SEGMENTS)
         return fail(PRHF_EINVAL, "1..%d segments per launch", PRHF_MAX_SEGMENTS);
-    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC)) return fail(PRHF_EINVAL, "unknown flag bits");
+    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE))
+        return fail(PRHF_EINVAL, "unknown flag bits");
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
-    if ((flags & PRHF_FLAG_ASYNC) && !dev) return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC needs device pointers");
+    if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
+        return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
 
     HIP_TRY(hipSetDevice(c->device));
 
@@ -148,6 +167,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     a.n_segs = n_segs;
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
     int launch_tier = 0;
+    bool want_pairs = false;
     for (int i = 0; i < n_segs; ++i) {
         const prhf_segment& u = segs[i];
         if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
@@ -167,14 +187,17 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.n_points = u.n_points;
         s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
-        plan_slice(s, n_freq);
+        // resident workgroups: LDS admits two per CU up to 80 KiB each, else one
+        plan_slice(s, n_freq, (long long)c->cu_count * (prhf::lds_bytes_for(n_alt) <= 80 * 1024 ? 2 : 1));
+        // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
+        want_pairs = want_pairs || (s.tier == 1 && u.n_points > 128 && u.prof_end > u.prof_begin);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
     // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup
     // the lowest indices so that a mixed launch does not end on its longest workgroups.
     std::stable_sort(a.seg, a.seg + n_segs, [](const prhf::SegDev& x, const prhf::SegDev& y) {
         auto cost = [](const prhf::SegDev& s) {
-            return (double)s.n_points / s.chunks / s.blocks_per_prof * (s.tier == 0 ? 3.5 : 1.0);
+            return (double)s.n_points / s.chunks / s.blocks_per_prof * (s.tier == 0 ? 3.5 : 1.0);   // head workgroups
         };
         return cost(x) > cost(y);
     });
@@ -182,7 +205,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         prhf::SegDev& s = a.seg[i];
         const long long P = s.prof_end - s.prof_begin;
         s.block_begin = blocks;
-        blocks += P * s.blocks_per_prof;
+        blocks += s.tail_prof * s.blocks_per_prof + (P - s.tail_prof) * s.tail_bpp;
         if (s.chunks > 1) {
             s.partial_off = partial_elems;
             s.altmin_off = altmin_elems;
@@ -261,6 +284,19 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (want_pairs) {
+        const bool stable = (flags & PRHF_FLAG_GRID_STABLE) != 0;
+        if (!(stable && c->pairs.p && c->pairs_src == a.mult && c->pairs_len == mult_len)) {
+            c->pairs_src = nullptr;
+            if ((rc = ensure(c, c->pairs, (size_t)mult_len * 16)) != PRHF_OK) return rc;
+            HIP_TRY(prhf::launch_grid_pairs(a.mult, mult_len, static_cast<double*>(c->pairs.p), c->stream));
+            if (stable) {
+                c->pairs_src = a.mult;
+                c->pairs_len = mult_len;
+            }
+        }
+        a.pairs = static_cast<const double*>(c->pairs.p);
+    }
     HIP_TRY(prhf::launch_vfo(a, blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
     if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -300,6 +336,8 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         const long long v = std::atoll(tw);
         if (v >= 64) kTargetWaves = v;
     }
+    if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
+    if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -323,6 +361,8 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         return fail(PRHF_EHIP, "context setup failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    (void)hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device);
+    if (c->cu_count < 1) c->cu_count = 256;
     *out = c;
     return PRHF_OK;
 }
@@ -334,6 +374,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->arena.p) (void)hipFree(c->arena.p);
     if (c->partial.p) (void)hipFree(c->partial.p);
     if (c->altmin.p) (void)hipFree(c->altmin.p);
+    if (c->pairs.p) (void)hipFree(c->pairs.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->d_words) (void)hipFree(c->d_words);
@@ -543,9 +584,11 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
     if (!c) return fail(PRHF_EINVAL, "null context");
     if (!vh_model || !vh_obs || (!residual_out && !cost_out)) return fail(PRHF_EINVAL, "null array pointer");
     if (n_prof < 0 || n_freq < 1 || n_freq > (1 << 20)) return fail(PRHF_EINVAL, "bad shape");
-    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC)) return fail(PRHF_EINVAL, "unknown flag bits");
+    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE))
+        return fail(PRHF_EINVAL, "unknown flag bits");
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
-    if ((flags & PRHF_FLAG_ASYNC) && !dev) return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC needs device pointers");
+    if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
+        return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
     if (n_prof == 0) return PRHF_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t pf = (size_t)n_prof * (size_t)n_freq;

@@ -41,6 +41,10 @@ struct SegDev {
     int chunk_len;                   // grid points per chunk (multiple of 64)
     int blocks_per_prof;
     int tier;                        // 0 faithful, 1 fast (read by the mixed-tier kernel)
+    // The last profiles of a long slice may be cut into more, shorter workgroups so that the launch
+    // drains quickly: profiles [tail_prof, P) of the slice use tail_bpp blocks each (tail_prof = P: none).
+    long long tail_prof;
+    int tail_bpp;
 };
 
 struct KArgs {
@@ -50,6 +54,7 @@ struct KArgs {
     const double* bpsi;
     const double* alt;
     const double* mult;
+    const double* pairs;             // (m_i, m_i+1 - m_i) interleaved, same indexing as mult; may be null
     double* out;
     double* partial;
     double* altmin;
@@ -68,6 +73,8 @@ inline size_t lds_bytes_for(long long n_alt) {
 
 hipError_t configure_kernels(size_t max_lds_bytes);
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
+// pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]
+hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words

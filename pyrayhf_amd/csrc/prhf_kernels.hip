@@ -3,7 +3,7 @@
 // One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its
 // stretched grid when few pairs are submitted.  A workgroup shares one profile: its
 // bottomside columns are staged once into LDS as 80-byte nodes, so that every grid point
-// costs five ds_read_b128 and no HBM traffic.  Per pair:
+// costs one LDS round trip (4 ds_read_b128 + 1 ds_read_b64) and no HBM traffic.  Per pair:
 //   S3-S6  reflection height: lanes stride over the levels, first level with X (or X+Y) > 1
 //          by ballot, running maximum below it by a wave max-reduce, np.interp semantics;
 //   S7-S10 lanes stride over the n_points stretched altitudes: locate the segment (closed
@@ -14,8 +14,8 @@
 //
 // Two arithmetic tiers (DESIGN.md "Arithmetic tiers"):
 //   TIER 0 "faithful": the reference's operation order, IEEE divide and sqrt, no contraction;
-//   TIER 1 "fast":     algebraically reduced mu' (57 FP64 operations + 2 v_rsq_f64 per point),
-//                      sin^2(psi) by a per-segment cubic, FMA contraction.
+//   TIER 1 "fast":     algebraically reduced mu' (45 FP64 operations + 2 v_rsq_f64 per point on
+//                      the main loop), sin^2(psi) by a per-segment cubic, FMA contraction.
 //
 // No MFMA: the work is elementwise float64 transcendental + reduction ("Roofline").
 
@@ -36,12 +36,18 @@ constexpr double kUnmagTol = 1e-12;                 // library.py:163
 constexpr double kLightKmS = 299792.458;            // library.py:70
 constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
 
-// One bottomside level.  u0..u3 depend on the tier and (fast tier) on the profile:
-//   faithful:            u0 = psi [deg], u1 = d(psi)/dz [deg/km]
-//   fast, segment turning psi by < kPolyAngle: sin^2(psi(z)) = u0 + dz*(u1 + dz*(u2 + dz*u3)), pad = 0
-//   fast, other segments:                     u0 = psi [rad], u1 = d(psi)/dz [rad/km],          pad = 1
+// One bottomside level = the left end of one np.interp segment [alt_j, alt_j+1): den, b are the
+// level values, sden, sb the np.interp slopes, and the abscissa is dz = z - alt_j.
+//   faithful tier: u0 = psi [deg], u1 = d(psi)/dz [deg/km]; dz is computed as the reference does.
+//   fast tier:     dz = m*span + off in one FMA, off = alt_0 - alt_j (z = m*span + alt_0, :413).
+//                  Segment turning psi by < kPolyAngle: sin^2(psi) = u0 + dz*(u1 + dz*(u2 + dz*u3));
+//                  other segments: u0 = psi_j [rad], u1 = d(psi)/dz [rad/km], u3 = NaN (the flag).
+// Everything is anchored at the LEFT level on purpose: below a steep layer den_j can be 0 (or
+// 1e-15 of den_j+1) and den_j + sden*dz keeps its relative accuracy there, which an expansion
+// about the segment centre would not (a density of -1e-6 m^-3 is enough to flip mu > 1, :238).
+// off sits next to alt so that the main loop reads off..u3 as 8 + 4 x 16 bytes.
 struct __attribute__((aligned(16))) Node {
-    double alt, den, sden, b, sb, u0, u1, u2, u3, pad;
+    double alt, off, den, sden, b, sb, u0, u1, u2, u3;
 };
 static_assert(sizeof(Node) == PRHF_NODE_BYTES, "node size");
 
@@ -143,14 +149,16 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 //   t = YL^2 (1-X), so alpha = h^2 + t (1-X) and dD/dX = -1 -+ t/beta                (:241-242)
 //   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
 // YL^2 = Y2 - Y2 S2 (absolute error 1e-16 Y2: harmless, YL^2 only enters through alpha and t).
-// index_fast_core leaves the mu > 1 cliff (:238) to the caller: *rad_out = fl(1 - q).  In vacuum
-// (X -> 0) mu is 1 to rounding, so the cliff must sit where the reference's does:
-//   sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) > 1 + 2^-52.
-constexpr double kRadCliff = 1.0000000000000002;
+// index_fast_core leaves the validity test (:233, :238) to the caller and hands out q = X(1-X)/D.
+// The reference keeps a point when 0 <= fl(1 - q) and sqrt(fl(1 - q)) <= 1.  In vacuum (X -> 0) mu
+// is 1 to rounding, so the upper cliff must sit where the reference's does:
+//   sqrt(fl(1 - q)) > 1  <=>  fl(1 - q) >= 1 + 2^-51  <=>  q <= -1.5 * 2^-52  (ties go to even);
+// below, mu^2 < 0 makes w (and with it q) NaN.  Hence: keep the point iff q > kQCliff.
+constexpr double kQCliff = -3.3306690738754696e-16;   // -1.5 * 2^-52
 
 template <int MODE>
 __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double* mu_out,
-                                                double* mup_out, double* rad_out) {
+                                                double* mup_out, double* q_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double Xm1 = 1.0 - X;
@@ -170,22 +178,23 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double mu = __builtin_fabs(Nw);
     const double rD = Nw * w;
     const double q = XXm1 * rD;
-    // bracket = 2X (2X - 1 + q dD/dX) + q Y dD/dY with dD/dX = -1 -+ t/beta (:241-242) and
-    // Y dD/dY = -2h +- (beta + h^2/beta), collected as 2X(2X - 1) + q [+-(beta + (h^2 - 2X t)/beta) - 2 (X + h)]
+    // half of the bracket 2X (2X - 1 + q dD/dX) + q Y dD/dY, with dD/dX = -1 -+ t/beta (:241-242) and
+    // Y dD/dY = -2h +- (beta + h^2/beta):  X (2X - 1) + q [+-(beta + (h^2 - 2X t)/beta)/2 - (X + h)],
+    // so that mu' = mu - bracket / (2 mu D) = mu - sign(D) w * half
     const double two_X = X + X;
-    const double inner = sgn * ((h2 - two_X * t) * rbeta + beta) - 2.0 * (X + h);
-    const double bracket = q * inner + (two_X * two_X - two_X);
-    const double A = __builtin_copysign(0.5 * w, D);
+    const double inner = (0.5 * sgn) * ((h2 - two_X * t) * rbeta + beta) - (X + h);
+    const double half = q * inner + (two_X * X - X);
+    const double A = __builtin_copysign(w, D);
     *mu_out = mu;
-    *mup_out = mu - A * bracket;
-    *rad_out = 1.0 - q;
+    *mup_out = mu - A * half;
+    *q_out = q;
 }
 
 template <int MODE>
 __device__ __forceinline__ void index_fast(double X, double Y2, double S2, double* mu_out, double* mup_out) {
-    double mu, mup, rad;
-    index_fast_core<MODE>(X, Y2, S2, &mu, &mup, &rad);
-    if (rad > kRadCliff) { mu = qnan(); mup = qnan(); }        // :238
+    double mu, mup, q;
+    index_fast_core<MODE>(X, Y2, S2, &mu, &mup, &q);
+    if (!(q > kQCliff)) { mu = qnan(); mup = qnan(); }         // :233, :238
     *mu_out = mu;
     *mup_out = mup;
 }
@@ -344,12 +353,12 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
             nd.alt = __builtin_inf();
-            nd.den = nd.sden = nd.b = nd.sb = nd.u0 = nd.u1 = nd.u2 = nd.u3 = nd.pad = 0.0;
+            nd.den = nd.sden = nd.b = nd.sb = nd.u0 = nd.u1 = nd.u2 = nd.u3 = nd.off = 0.0;
             nodes[k] = nd;
             continue;
         }
         const double a = alt[k], d = den[k], b = bmag[k], p = bpsi[k];
-        nd.alt = a; nd.den = d; nd.b = b; nd.pad = 0.0;
+        nd.alt = a; nd.den = d; nd.b = b; nd.off = 0.0;
         double spsi = 0.0, turn = 0.0;
         if (k + 1 < K) {
             const double da = alt[k + 1] - a;
@@ -364,20 +373,22 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         }
         if (TIER == 0) {
             nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0; nd.u3 = 0.0;
-        } else if (turn < kPolyAngle) {
-            // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
-            const double r = spsi * kDegToRad;
-            double sp, cp;
-            sincos(p * kDegToRad, &sp, &cp);
-            const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
-            nd.u0 = sp * sp;
-            nd.u1 = s2p * r;
-            nd.u2 = c2p * (r * r);
-            nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
-        } else {                                   // this segment turns the field too far for the cubic
-            nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = 0.0;
-            nd.pad = 1.0;
-            trig = 1;
+        } else {
+            nd.off = alt[0] - a;
+            if (turn < kPolyAngle) {
+                // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
+                const double r = spsi * kDegToRad;
+                double sp, cp;
+                sincos(p * kDegToRad, &sp, &cp);
+                const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
+                nd.u0 = sp * sp;
+                nd.u1 = s2p * r;
+                nd.u2 = c2p * (r * r);
+                nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
+            } else {                               // this segment turns the field too far for the cubic
+                nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
+                trig = 1;
+            }
         }
         nodes[k] = nd;
         const double fn = sqrt(d) * kPlasma;       // :96
@@ -457,7 +468,7 @@ __device__ __forceinline__ int guess_segment(const unsigned short* __restrict__ 
     return j;
 }
 
-// mu' at abscissa offset dz >= 0 inside the segment that starts at node nd.
+// mu' at abscissa offset dz = z - alt_j >= 0 inside the segment that starts at node nd.
 template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_hz, double f2, double cX,
                                             double cY2, bool poly_angle) {
@@ -485,7 +496,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             const double b = nd.sb * dz + nd.b;
             const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
             double S2;
-            if (poly_angle || nd.pad == 0.0) {         // per segment; poly_angle: true for the whole profile
+            if (poly_angle || nd.u3 == nd.u3) {        // per segment; poly_angle: true for the whole profile
                 S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
             } else {
                 const double sn = sin(nd.u0 + nd.u1 * dz);
@@ -498,38 +509,52 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 }
 
 // One grid point per lane on the lean path of the fast tier (uniform altitude grid, every segment
-// on the sin^2 cubic, z >= alt[0], not the last grid point): returns mu' * dh, or 0 where the
-// reference's term is NaN (:233, :238, :288).
+// on the sin^2 cubic, span >= 0, not the last grid point).  g = (m_i, m_i+1 - m_i) from the pair
+// table; returns acc + mu' * (m_i+1 - m_i), or acc where the reference's term is NaN (:233, :238,
+// :288) - the caller multiplies the sum by span once (:415).
 template <int MODE>
-__device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double m0, double m1,
-                                            double span, double a0, double kj, double cX, double cY2) {
+__device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
+                                            double a0, double kj, double cX, double cY2, double acc) {
 #pragma clang fp contract(fast)
-    const double z = __builtin_fma(m0, span, a0);              // :413
-    const double dh = (m1 - m0) * span;                        // :415
-    // 0 <= m <= 1 puts (int)(m * kj) inside [0, K-1]; the unsigned min only guards the LDS address
-    // against a caller-supplied multiplier outside [0, 1] (it also folds a negative index to K-1)
+    const double m0 = g.x;
+    // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
+    // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here
+#ifdef PRHF_LEAN_CLAMP
     int j = (int)min((unsigned)(int)(m0 * kj), (unsigned)(K - 1));
-    const Node* pn = reinterpret_cast<const Node*>(reinterpret_cast<const char*>(nodes) +
-                                                   __umul24((unsigned)j, (unsigned)sizeof(Node)));
-    Node nd = pn[0];
-    const double an = pn[1].alt;                               // node K is a +inf sentinel
+#else
+    int j = (int)(m0 * kj);
+#endif
+    const char* pn = static_cast<const char*>(__builtin_assume_aligned(
+        reinterpret_cast<const char*>(nodes) + __umul24((unsigned)j, (unsigned)sizeof(Node)), 16));
+    double off = *reinterpret_cast<const double*>(pn + 8);
+    double2 dd = *reinterpret_cast<const double2*>(pn + 16);       // den, sden
+    double2 bb = *reinterpret_cast<const double2*>(pn + 32);       // b, sb
+    double2 ua = *reinterpret_cast<const double2*>(pn + 48);       // u0, u1
+    double2 ub = *reinterpret_cast<const double2*>(pn + 64);       // u2, u3
     // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
-    asm volatile("" :: "v"(nd.den), "v"(nd.sden), "v"(nd.b), "v"(nd.sb), "v"(nd.u0), "v"(nd.u1), "v"(nd.u2),
-                 "v"(nd.u3));
-    if (__builtin_expect(__any(z < nd.alt || z >= an), 0)) {   // restore np.interp's exact segment
+    asm volatile("" :: "v"(dd.x), "v"(dd.y), "v"(bb.x), "v"(bb.y), "v"(ua.x), "v"(ua.y), "v"(ub.x), "v"(ub.y));
+    double x = __builtin_fma(m0, span, off);                   // z - alt_j with z = m*span + a0 (:413)
+    // The closed-form index can miss by one where z rounds onto a level.  One segment too low is
+    // harmless (a linear piece evaluated 1e-13 km past its end); one too high would extrapolate to
+    // the LEFT of level j, where a zero density turns negative: that side restores np.interp's
+    // exact segment alt[j] <= z < alt[j+1].
+    if (__builtin_expect(__any(x < 0.0), 0)) {
+        const double z = __builtin_fma(m0, span, a0);
         while (j > 0 && z < nodes[j].alt) --j;
         while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
-        nd = nodes[j];
+        const Node nd = nodes[j];
+        off = nd.off; dd = make_double2(nd.den, nd.sden); bb = make_double2(nd.b, nd.sb);
+        ua = make_double2(nd.u0, nd.u1); ub = make_double2(nd.u2, nd.u3);
+        x = fmax(__builtin_fma(m0, span, off), 0.0);
     }
-    const double dz = z - nd.alt;                              // >= 0: span >= 0 and alt[j] <= z
-    const double den = nd.sden * dz + nd.den;
-    const double b = nd.sb * dz + nd.b;
-    const double S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
-    double mu, mup, rad;
-    index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &rad);
-    // a NaN anywhere upstream makes rad NaN (it is 1 - X(1-X)/D with 1/D from the same rsqrt as mu),
-    // so one comparison covers :233, :238 and the nansum
-    return (rad <= kRadCliff) ? mup * dh : 0.0;
+    const double den = dd.y * x + dd.x;
+    const double b = bb.y * x + bb.x;
+    const double S2 = ua.x + x * (ua.y + x * (ub.x + x * ub.y));
+    double mu, mup, q;
+    index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &q);
+    // a NaN anywhere upstream makes q NaN (it is X(1-X)/D with 1/D from the same rsqrt as mu), so one
+    // comparison covers :233, :238 and the nansum
+    return __builtin_fma((q > kQCliff) ? mup : 0.0, g.y, acc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -540,8 +565,8 @@ template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes,
                                                   const unsigned short* __restrict__ hint,
                                                   const BlockInfo& info, const double* __restrict__ mult,
-                                                  int n_points, int i0, int i1, double f_hz, double f2,
-                                                  double h_refl, int lane) {
+                                                  const double2* __restrict__ pairs, int n_points, int i0,
+                                                  int i1, double f_hz, double f2, double h_refl, int lane) {
     const int K = info.K;
     const double a0 = info.a0;
     const double span = uniform(h_refl - a0);      // :413 (critical_height - aalt[0])
@@ -552,7 +577,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     const int last = n_points - 1;
     double acc = 0.0;
     int first = i0;                                // first grid point of the next wave-iteration
-    if (TIER == 1 && !UNMAG && poly_angle && info.uniform) {
+    if (TIER == 1 && !UNMAG && poly_angle && info.uniform && pairs != nullptr) {
         // Lean main loop of the common case (uniform altitude grid, slowly turning field):
         // whole wave-iterations that neither touch the last grid point nor need lane masks,
         // so there is no index clamping, no exec masking and the loop control is scalar.
@@ -561,33 +586,33 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         first = uniform(first);
         const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
         const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
-        if (first + 128 <= full_end && span >= 0.0) {         // span < 0: left clamp, generic loop
-            // 0 <= m <= 1 and span < alt[K-1] - a0, so (int)(m * kj) is already inside [0, K-2].
+        // span < 0: left clamp, generic loop; kj <= K - 1 keeps the closed-form index inside the node table
+        if (first + 128 <= full_end && span >= 0.0 && kj <= (double)(K - 1)) {
             double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
             asm volatile("" : "+v"(a0v));
-            const double* pm = mult + lane;
-            double m0 = pm[first], m1 = pm[first + 1];
+            const double2* pp = pairs + lane;
+            double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
+            double2 g0 = pp[first];
 #if PRHF_LEAN_UNROLL == 2
             // two wave-iterations per trip so that the prefetch registers swap roles without moves
             for (; first + 192 <= full_end; first += 128) {
-                const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
-                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
-                m0 = pm[first + 128];
-                m1 = pm[first + 129];
-                acc += lean_step<MODE>(nodes, K, n0, n1, span, a0v, kj, cX, cY2);
+                const double2 g1 = pp[first + 64];             // next iteration, in bounds
+                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
+                g0 = pp[first + 128];
+                accm = lean_step<MODE>(nodes, K, g1, span, a0v, kj, cX, cY2, accm);
             }
             if (first + 128 <= full_end) {                     // odd wave-iteration left over
-                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
+                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
                 first += 64;
             }
 #else
             for (; first + 128 <= full_end; first += 64) {
-                const double n0 = pm[first + 64], n1 = pm[first + 65];     // next iteration, in bounds
-                acc += lean_step<MODE>(nodes, K, m0, m1, span, a0v, kj, cX, cY2);
-                m0 = n0;
-                m1 = n1;
+                const double2 g1 = pp[first + 64];             // next iteration, in bounds
+                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
+                g0 = g1;
             }
 #endif
+            acc = accm * span;                                 // :415: dh = (m_i+1 - m_i) * span
         }
     }
     int i = first + lane;
@@ -621,8 +646,13 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
             nd = nodes[j];
         }
-        double dz = z - nd.alt;
-        if (dz < 0.0) dz = 0.0;                    // z below the first level: left value
+        double dz;
+        if (TIER == 0) {
+            dz = z - nd.alt;
+            if (dz < 0.0) dz = 0.0;                // z below the first level: left value
+        } else {
+            dz = fmax(__builtin_fma(m0, span, nd.off), 0.0);       // 0: z below the first level, left value
+        }
         const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY2, poly_angle);
         const double term = mup * dh;              // :288
         if (term == term) acc = acc + term;        // nansum
@@ -636,15 +666,17 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
-                                          const BlockInfo& info, long long prof_local, int block_in_prof) {
+                                          const BlockInfo& info, long long prof_local, int block_in_prof,
+                                          int blocks_per_prof) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int F = (int)a.n_freq;
     const int C = sg.chunks;
     const long long T = (long long)F * C;
     const double* mult = a.mult + sg.mult_off;
+    const double2* pairs = a.pairs ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
-    for (long long t = (long long)block_in_prof * W + wave; t < T; t += (long long)sg.blocks_per_prof * W) {
+    for (long long t = (long long)block_in_prof * W + wave; t < T; t += (long long)blocks_per_prof * W) {
         const int f = (int)(t % F);
         const int c = (int)(t / F);
         double result = qnan();
@@ -659,11 +691,11 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
                 if (info.unmag)
-                    result = integrate_chunk<MODE, TIER, true>(nodes, hint, info, mult, sg.n_points, i0, i1,
+                    result = integrate_chunk<MODE, TIER, true>(nodes, hint, info, mult, pairs, sg.n_points, i0, i1,
                                                                f_hz, f2, h, lane);
                 else
-                    result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, sg.n_points, i0, i1,
-                                                                f_hz, f2, h, lane);
+                    result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, sg.n_points, i0,
+                                                                i1, f_hz, f2, h, lane);
             } else if (info.K == 1) {
                 // A one-level bottomside: np.interp with a single node returns that node even
                 // for the NaN abscissae of an escaping frequency (numpy arr_interp, lenxp == 1),
@@ -699,7 +731,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 template <int TIER, int THREADS>
 __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
                                           unsigned short* hint, double* red, long long prof_local,
-                                          int block_in_prof) {
+                                          int block_in_prof, int blocks_per_prof) {
     const long long p = sg.prof_begin + prof_local;
     const BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
@@ -709,9 +741,11 @@ __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
     }
     if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+                                               blocks_per_prof);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof);
+        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+                                               blocks_per_prof);
 }
 
 // TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
@@ -730,14 +764,42 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     int s = 0;
     while (s + 1 < a.n_segs && bid >= a.seg[s + 1].block_begin) ++s;
     const SegDev& sg = a.seg[s];
-    const long long lb = bid - sg.block_begin;
-    const long long prof_local = lb / sg.blocks_per_prof;
-    const int block_in_prof = (int)(lb % sg.blocks_per_prof);
+    long long lb = bid - sg.block_begin;
+    const long long head_blocks = sg.tail_prof * sg.blocks_per_prof;
+    int bpp = sg.blocks_per_prof;
+    long long prof0 = 0;
+    if (lb >= head_blocks) {                   // the slice's tail: more, shorter workgroups per profile
+        lb -= head_blocks;
+        bpp = sg.tail_bpp;
+        prof0 = sg.tail_prof;
+    }
+    const long long prof_local = prof0 + lb / bpp;
+    const int block_in_prof = (int)(lb % bpp);
 
     if (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-        run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof);
+        run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp);
     else
-        run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof);
+        run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp);
+}
+
+// Pair table of the fast tier's main loop: (m_i, m_i+1 - m_i) side by side, one 16-byte load per
+// grid point.  Runs over the whole (possibly concatenated) multiplier array; the difference that
+// straddles two grids belongs to a last grid point, which the main loop never touches.
+// m is clamped to the unit interval the stretched grid lives on (library.py:361-364) - a no-op for
+// every grid the reference can produce - so that the main loop's LDS index needs no clamp of its
+// own whatever the caller passed (fmax/fmin also turn a NaN into 0).
+__global__ void grid_pairs_kernel(const double* __restrict__ mult, long long n, double2* __restrict__ pairs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = mult[i];
+    pairs[i] = make_double2(fmin(fmax(m, 0.0), 1.0), (i + 1 < n ? mult[i + 1] : m) - m);
+}
+
+hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(grid_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mult, n,
+                       reinterpret_cast<double2*>(pairs));
+    return hipGetLastError();
 }
 
 // Chunked pairs: add the chunk sums in a fixed order, then the reference's 0 -> NaN and + min(alt).

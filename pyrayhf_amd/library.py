@@ -244,10 +244,7 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
     if a.shape[-1] != n_alt or (a.dim() == 2 and a.shape[0] != n_prof):
         raise ValueError("alt must have one value per density level")
     alt_stride = n_alt if a.dim() == 2 else 0
-    key = (int(n_points), dev.index)
-    mult = _torch_mult.get(key)
-    if mult is None:
-        mult = _torch_mult[key] = torch.as_tensor(_multiplier(n_points), device=dev)
+    mult, grid_flag = _device_grid((int(n_points),), dev)
     if out is None:
         out = torch.empty((n_prof, f.numel()), dtype=torch.float64, device=dev)
     elif out.shape != (n_prof, f.numel()) or out.dtype != torch.float64 or not out.is_contiguous():
@@ -257,7 +254,7 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
     ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
                        n_prof, n_alt, n_alt, alt_stride, mult.data_ptr(), int(n_points), mode_code,
-                       out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC)
+                       out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC | grid_flag)
     _native.raise_for(rc)
     if sync:
         _native.raise_for(ctx.sync())
@@ -265,6 +262,22 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
 
 
 _torch_mult = {}
+
+
+def _device_grid(n_points_list, dev):
+    """Concatenated stretched grids as a device tensor, and the flag that tells the library whether
+    the tensor is one of the cached (never freed, never written) ones whose derived tables it may keep."""
+    import torch
+
+    key = (tuple(n_points_list), dev.index)
+    mult = _torch_mult.get(key)
+    if mult is not None:
+        return mult, _native.FLAG_GRID_STABLE
+    mult = torch.as_tensor(np.concatenate([_multiplier(n) for n in n_points_list]), device=dev)
+    if len(_torch_mult) < 64:            # entries are never evicted: a freed address could come back with other contents
+        _torch_mult[key] = mult
+        return mult, _native.FLAG_GRID_STABLE
+    return mult, 0
 
 
 def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200, *,
@@ -352,25 +365,25 @@ def _torch_mixed(freq, den, bmag, bpsi, alt, segments, math, sync=True):
     n_prof, n_alt = d2.shape
     if a.shape[-1] != n_alt or (a.dim() == 2 and a.shape[0] != n_prof):
         raise ValueError("alt must have one value per density level")
-    segs, grids, off = [], [], 0
+    segs, sizes, off = [], [], 0
     for (p0, p1, mode, n_points) in segments:
-        m = _multiplier(n_points)
+        n = _multiplier(n_points).size
         segs.append(_native.Segment(int(p0), int(p1), _mode_code(mode), int(n_points), off, int(p0) * f.numel()))
-        grids.append(m)
-        off += m.size
+        sizes.append(n)
+        off += n
     out = torch.full((n_prof, f.numel()), float("nan"), dtype=torch.float64, device=dev)
     if not segs:
         return out
-    mult = torch.as_tensor(np.concatenate(grids), device=dev)
+    mult, grid_flag = _device_grid(sizes, dev)
     ctx = _native.context(dev.index if dev.index is not None else torch.cuda.current_device())
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.set_math(_default_math(None, math))
     rc = ctx.vfo_worklist(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
                           n_prof, n_alt, n_alt, n_alt if a.dim() == 2 else 0, mult.data_ptr(), mult.numel(), segs,
-                          out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC)
+                          out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC | grid_flag)
     _native.raise_for(rc)
-    if sync:
-        _native.raise_for(ctx.sync())          # also keeps `mult` alive until the kernel has read it
+    if sync or not grid_flag:
+        _native.raise_for(ctx.sync())          # an uncached `mult` must stay alive until the kernel has read it
     return out
 
 
