@@ -38,6 +38,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
+int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
 constexpr long long kMaxAlt = 1600;        // nodes + hints must fit 160 KiB of LDS
@@ -64,7 +65,7 @@ struct prhf_ctx {
     DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
-    unsigned* d_status = nullptr;
+    unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1] block queue of persistent launches
     unsigned* h_status = nullptr;   // pinned
     unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
     unsigned long long* h_words = nullptr;   // pinned
@@ -168,6 +169,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
     int launch_tier = 0;
     bool want_pairs = false;
+    // resident workgroups: LDS admits two per CU up to 80 KiB each, else one
+    const long long wg_slots = (long long)c->cu_count * (prhf::lds_bytes_for(n_alt) <= 80 * 1024 ? 2 : 1);
     for (int i = 0; i < n_segs; ++i) {
         const prhf_segment& u = segs[i];
         if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
@@ -187,8 +190,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.n_points = u.n_points;
         s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
-        // resident workgroups: LDS admits two per CU up to 80 KiB each, else one
-        plan_slice(s, n_freq, (long long)c->cu_count * (prhf::lds_bytes_for(n_alt) <= 80 * 1024 ? 2 : 1));
+        plan_slice(s, n_freq, wg_slots);
         // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
         want_pairs = want_pairs || (s.tier == 1 && u.n_points > 128 && u.prof_end > u.prof_begin);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
@@ -297,7 +299,35 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         }
         a.pairs = static_cast<const double*>(c->pairs.p);
     }
-    HIP_TRY(prhf::launch_vfo(a, blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+#ifdef PRHF_TRACE
+    // diagnostics build (tools/wave_trace.py): per-wave wall-clock stamps of this launch, dumped to $PRHF_TRACE_FILE
+    static DevBuf trace_buf;
+    const size_t trace_words = (size_t)blocks * kWavesPerBlock * 2;
+    if (std::getenv("PRHF_TRACE_FILE")) {
+        if ((rc = ensure(c, trace_buf, trace_words * 8)) != PRHF_OK) return rc;
+        HIP_TRY(hipMemsetAsync(trace_buf.p, 0, trace_words * 8, c->stream));
+        a.trace = static_cast<unsigned long long*>(trace_buf.p);
+    }
+#endif
+    a.n_blocks = blocks;
+    long long grid_blocks = blocks;
+    if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
+        a.queue = c->d_status + 1;
+        grid_blocks = wg_slots;
+        HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), c->stream));
+    }
+    HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+#ifdef PRHF_TRACE
+    if (a.trace) {
+        std::vector<unsigned long long> host(trace_words);
+        HIP_TRY(hipMemcpyAsync(host.data(), a.trace, trace_words * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (FILE* fp = std::fopen(std::getenv("PRHF_TRACE_FILE"), "wb")) {
+            std::fwrite(host.data(), 8, trace_words, fp);
+            std::fclose(fp);
+        }
+    }
+#endif
     if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -336,6 +366,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         const long long v = std::atoll(tw);
         if (v >= 64) kTargetWaves = v;
     }
+    if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;
@@ -349,10 +380,10 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 2 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
             hipSuccess ||
-        (e = hipMemset(c->d_status, 0, sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_status, 0, 2 * sizeof(unsigned))) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_words), 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 2 * sizeof(unsigned long long),
                            hipHostMallocDefault)) != hipSuccess ||

@@ -59,6 +59,9 @@ struct KArgs {
     double* partial;
     double* altmin;
     unsigned* status;
+    unsigned* queue;                 // persistent launch: next block index - gridDim.x, zero at launch; null = one block per workgroup
+    long long n_blocks;              // blocks of work in this launch
+    unsigned long long* trace;       // -DPRHF_TRACE builds: (start, end) wall clock of every wave, else unused
     long long n_freq, n_alt, prof_stride, alt_stride;
     int n_segs;
     SegDev seg[PRHF_MAX_SEGMENTS];
@@ -76,7 +79,9 @@ hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
 // pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
-hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream);
+// a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull
+// block indices from the queue, else grid_blocks must equal a.n_blocks
+hipError_t launch_vfo(const KArgs& a, long long grid_blocks, int tier, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
                          unsigned long long* absmax_scratch, unsigned long long* absmax_host,

@@ -590,15 +590,31 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         if (first + 128 <= full_end && span >= 0.0 && kj <= (double)(K - 1)) {
             double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
             asm volatile("" : "+v"(a0v));
-            const double2* pp = pairs + lane;
+            // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
+            // SGPR, so the loop spends no vector instruction on addresses (and reads past the table
+            // would return 0 instead of faulting).
+            const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double2*>(pairs), 0, n_points * (int)sizeof(double2), 0x00020000);
+#ifdef PRHF_PAIR_GLOBAL
+            auto grid_at = [&](int i) { return pairs[i + lane]; };
+#else
+            auto grid_at = [&](int i) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
+                double2 g;
+                __builtin_memcpy(&g, &v, sizeof g);
+                return g;
+            };
+#endif
             double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
-            double2 g0 = pp[first];
+            double2 g0 = grid_at(first);
 #if PRHF_LEAN_UNROLL == 2
             // two wave-iterations per trip so that the prefetch registers swap roles without moves
             for (; first + 192 <= full_end; first += 128) {
-                const double2 g1 = pp[first + 64];             // next iteration, in bounds
+                const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
                 accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-                g0 = pp[first + 128];
+                g0 = grid_at(first + 128);
                 accm = lean_step<MODE>(nodes, K, g1, span, a0v, kj, cX, cY2, accm);
             }
             if (first + 128 <= full_end) {                     // odd wave-iteration left over
@@ -607,7 +623,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             }
 #else
             for (; first + 128 <= full_end; first += 64) {
-                const double2 g1 = pp[first + 64];             // next iteration, in bounds
+                const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
                 accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
                 g0 = g1;
             }
@@ -667,16 +683,25 @@ template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
                                           const BlockInfo& info, long long prof_local, int block_in_prof,
-                                          int blocks_per_prof) {
+                                          int blocks_per_prof, int* item_next) {
     constexpr int W = THREADS / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int F = (int)a.n_freq;
     const int C = sg.chunks;
     const long long T = (long long)F * C;
     const double* mult = a.mult + sg.mult_off;
     const double2* pairs = a.pairs ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
-    for (long long t = (long long)block_in_prof * W + wave; t < T; t += (long long)blocks_per_prof * W) {
+    // Items are handed out first come, first served.  The SIMD arbiter favours its older waves: with a
+    // fixed share per wave, waves 0-3 of a workgroup were done at 70 % of its life (tools/wave_trace.py)
+    // and their slots sat empty for the rest.  Which wave computes a pair does not change its value.
+    for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(item_next, 1);
+        u = uniform(u);
+        // this block's items: rounds of W, interleaved with the profile's other blocks
+        const long long t = (long long)(u / W) * blocks_per_prof * W + (long long)block_in_prof * W + (u % W);
+        if (t >= T) break;
         const int f = (int)(t % F);
         const int c = (int)(t / F);
         double result = qnan();
@@ -731,7 +756,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 template <int TIER, int THREADS>
 __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
                                           unsigned short* hint, double* red, long long prof_local,
-                                          int block_in_prof, int blocks_per_prof) {
+                                          int block_in_prof, int blocks_per_prof, int* item_next) {
     const long long p = sg.prof_begin + prof_local;
     const BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
@@ -742,10 +767,10 @@ __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node
     }
     if (sg.mode == PRHF_KMODE_O)
         run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
-                                               blocks_per_prof);
+                                               blocks_per_prof, item_next);
     else
         run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
-                                               blocks_per_prof);
+                                               blocks_per_prof, item_next);
 }
 
 // TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
@@ -760,26 +785,52 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
                                             kHintBuckets * sizeof(unsigned short));
 
-    const long long bid = blockIdx.x;
-    int s = 0;
-    while (s + 1 < a.n_segs && bid >= a.seg[s + 1].block_begin) ++s;
-    const SegDev& sg = a.seg[s];
-    long long lb = bid - sg.block_begin;
-    const long long head_blocks = sg.tail_prof * sg.blocks_per_prof;
-    int bpp = sg.blocks_per_prof;
-    long long prof0 = 0;
-    if (lb >= head_blocks) {                   // the slice's tail: more, shorter workgroups per profile
-        lb -= head_blocks;
-        bpp = sg.tail_bpp;
-        prof0 = sg.tail_prof;
-    }
-    const long long prof_local = prof0 + lb / bpp;
-    const int block_in_prof = (int)(lb % bpp);
+    // Long launches are persistent: as many workgroups as the device keeps resident, each pulling the
+    // next block of work from a queue when it finishes one.  (Left to the hardware dispatcher, the
+    // very uneven workgroup lifetimes - 0.7 to 5.7 ms at n_points = 20000 - leave ~12 % of the
+    // workgroup slots empty: measured with tools/wave_trace.py.)  Every wave leaves the loop through
+    // the same uniform test, so the grid always drains.
+    __shared__ long long next_bid;
+    __shared__ int item_next;
+    long long bid = blockIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) item_next = 0;   // ordered before its first use by the barriers of stage_profile
+#ifdef PRHF_TRACE
+        const unsigned long long t_start = wall_clock64();
+#endif
+        int s = 0;
+        while (s + 1 < a.n_segs && bid >= a.seg[s + 1].block_begin) ++s;
+        const SegDev& sg = a.seg[s];
+        long long lb = bid - sg.block_begin;
+        const long long head_blocks = sg.tail_prof * sg.blocks_per_prof;
+        int bpp = sg.blocks_per_prof;
+        long long prof0 = 0;
+        if (lb >= head_blocks) {               // the slice's tail: more, shorter workgroups per profile
+            lb -= head_blocks;
+            bpp = sg.tail_bpp;
+            prof0 = sg.tail_prof;
+        }
+        const long long prof_local = prof0 + lb / bpp;
+        const int block_in_prof = (int)(lb % bpp);
 
-    if (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-        run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp);
-    else
-        run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp);
+        if (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
+            run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
+        else
+            run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
+#ifdef PRHF_TRACE
+        if (a.trace && (threadIdx.x & 63) == 0) {
+            unsigned long long* t = a.trace + (bid * (THREADS / 64) + (threadIdx.x >> 6)) * 2;
+            t[0] = t_start;
+            t[1] = wall_clock64();
+        }
+#endif
+        if (a.queue == nullptr) break;
+        __syncthreads();                       // every wave is done with the staged profile (and with next_bid)
+        if (threadIdx.x == 0) next_bid = (long long)gridDim.x + atomicAdd(a.queue, 1u);
+        __syncthreads();
+        bid = uniform((int)next_bid);
+        if (bid >= a.n_blocks) break;
+    }
 }
 
 // Pair table of the fast tier's main loop: (m_i, m_i+1 - m_i) side by side, one 16-byte load per
@@ -862,7 +913,7 @@ __global__ void absmax_kernel(const double* __restrict__ Y, long long n, unsigne
 
 hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_bytes, hipStream_t stream) {
     constexpr int THREADS = PRHF_BLOCK_THREADS;
-    if (n_blocks <= 0) return hipSuccess;
+    if (n_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
     if (tier == 0)
         hipLaunchKernelGGL((vfo_kernel<0, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
     else if (tier == 1)
