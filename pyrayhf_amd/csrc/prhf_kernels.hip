@@ -156,7 +156,9 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 // below, mu^2 < 0 makes w (and with it q) NaN.  Hence: keep the point iff q > kQCliff.
 constexpr double kQCliff = -3.3306690738754696e-16;   // -1.5 * 2^-52
 
-template <int MODE>
+// POSD: the caller knows D > 0 (true wherever X + Y < 1 in X mode and X < 1 in O mode, i.e. on the
+// integration path below the reflection height) and skips the sign transfer.
+template <int MODE, bool POSD = false>
 __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double* mu_out,
                                                 double* mup_out, double* q_out) {
 #pragma clang fp contract(fast)
@@ -184,7 +186,7 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double two_X = X + X;
     const double inner = (0.5 * sgn) * ((h2 - two_X * t) * rbeta + beta) - (X + h);
     const double half = q * inner + (two_X * X - X);
-    const double A = __builtin_copysign(w, D);
+    const double A = POSD ? w : __builtin_copysign(w, D);
     *mu_out = mu;
     *mup_out = mu - A * half;
     *q_out = q;
@@ -551,10 +553,16 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     const double b = bb.y * x + bb.x;
     const double S2 = ua.x + x * (ua.y + x * (ub.x + x * ub.y));
     double mu, mup, q;
-    index_fast_core<MODE>(den * cX, (b * b) * cY2, S2, &mu, &mup, &q);
-    // a NaN anywhere upstream makes q NaN (it is X(1-X)/D with 1/D from the same rsqrt as mu), so one
-    // comparison covers :233, :238 and the nansum
-    return __builtin_fma((q > kQCliff) ? mup : 0.0, g.y, acc);
+    index_fast_core<MODE, true>(den * cX, (b * b) * cY2, S2, &mu, &mup, &q);
+    // Validity (:233, :238) on this path, where 0 <= X and X (+ Y) < 1 hold at every level below the
+    // reflection height and therefore between the levels (all three interpolants are linear):
+    //   D > 0:  O mode D = (1-X) - h + beta >= 1-X;  X mode D > 0 <=> (1-X)(1 - YL^2) > YT^2, which
+    //           1-X > Y, Y < 1 imply;
+    //   hence q = X(1-X)/D >= 0 and the mu > 1 cliff (:238) cannot trigger;
+    //   mu^2 < 0 (:233) only by rounding at the last grid points: there w = rsqrt(N D) and mu' are NaN.
+    // The group index c/v_g of a propagating mode is positive, so max(mu', 0) - which returns 0 for a
+    // NaN - is the nansum's selection in one instruction.
+    return __builtin_fma(fmax(mup, 0.0), g.y, acc);
 }
 
 // ---------------------------------------------------------------------------------------
