@@ -128,7 +128,8 @@ def main():
     p_total = p_gpu * world
     freq = np.linspace(0.5, 16.0, n_freq)                       # config 4 sweep
     lo, hi = pdist.shard_bounds(p_total, world, rank)
-    alt, den, bmag, bpsi = synth.chapman_profiles(p_total, 20260004, rows=slice(lo, hi))
+    # always the rows of config 4's 100 000-profile draw: N = 1 is its first shard, N = 8 the whole of it
+    alt, den, bmag, bpsi = synth.chapman_profiles(max(p_total, 100000), 20260004, rows=slice(lo, hi))
     t = {k: torch.as_tensor(v, device=dev) for k, v in
          (("freq", freq), ("alt", alt), ("den", den), ("bmag", bmag), ("bpsi", bpsi))}
     out = torch.empty((p_gpu, n_freq), dtype=torch.float64, device=dev)

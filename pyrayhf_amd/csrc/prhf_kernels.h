@@ -20,7 +20,7 @@
 #endif
 #define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
-#define PRHF_RED_DOUBLES 128        // block-reduction scratch (8 rows x up to 16 waves)
+#define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 80          // one staged bottomside level
 #ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128

@@ -270,11 +270,18 @@ struct BlockInfo {
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
     int poly_angle;   // fast tier: sin^2(psi) cubic per segment is valid
-    double alt_min;   // min over the whole altitude column (:507)
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
     double inv_step;  // 1 / level spacing (uniform grids)
 };
+
+// Per-profile scalars that are read once per pair only live in LDS (in the reduction scratch, behind its
+// 9 rows) rather than in SGPRs: the main loop needs every scalar register it can get.
+enum { kKeepAltMin = 0,     // min over the whole altitude column (:507)
+       kKeepPf2Max = 1,     // max f_N^2 over the bottomside levels
+       kKeepGbMax = 2 };    // g_p max|B| over the bottomside levels
+template <int THREADS>
+__device__ __forceinline__ const double* kept_scalars(const double* red) { return red + 9 * (THREADS / 64); }
 
 constexpr int kHintBuckets = PRHF_HINT_BUCKETS;
 
@@ -289,10 +296,11 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                                                    unsigned short* hint, double* red) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
-    static_assert(8 * W <= PRHF_RED_DOUBLES, "reduction scratch too small");
+    static_assert(9 * W + 3 <= PRHF_RED_DOUBLES, "reduction scratch too small");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // red rows of W doubles: 0 peak value, 1 peak index, 2 alt min, 3 freq min,
-    //                        4 |B| max, 5 negative density, 6 max angle step, 7 non-uniform grid
+    //                        4 |B| max, 5 negative density, 6 max angle step, 7 non-uniform grid,
+    //                        8 f_N^2 max below the peak
     // ---- phase 1: first-occurrence argmax of density, min altitude, min frequency ---------
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
@@ -333,7 +341,8 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     }
     BlockInfo info;
     info.K = uniform((bi == 0x7fffffff) ? 0 : bi);      // library.py:371-375: levels [0, argmax)
-    info.alt_min = uniform(amin);
+    // every thread holds the same reduced value and writes it: a wave reads back what it wrote itself
+    red[9 * W + kKeepAltMin] = amin;
     fm = uniform(fm);
     info.bad = 0;
     info.unmag = 0;
@@ -349,7 +358,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     }
     // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
-    double bmax = 0.0;
+    double bmax = 0.0, pmax = 0.0;
     int neg = 0, ragged = 0, trig = 0;
     for (int k = tid; k <= K; k += THREADS) {
         Node nd;
@@ -396,10 +405,12 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         const double fn = sqrt(d) * kPlasma;       // :96
         pf2[k] = fn * fn;                          // :136 numerator
         gb[k] = kGyro * b;                         // :157 numerator
+        pmax = fmax(pmax, fn * fn);
         bmax = fmax(bmax, fabs(b));
         neg |= (d < 0.0) ? 1 : 0;
     }
     bmax = wave_max(bmax);
+    pmax = wave_max(pmax);
     neg = __any(neg) ? 1 : 0;
     ragged = __any(ragged) ? 1 : 0;
     trig = __any(trig) ? 1 : 0;
@@ -408,8 +419,10 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         red[5 * W + wave] = (double)neg;
         red[6 * W + wave] = (double)trig;
         red[7 * W + wave] = (double)ragged;
+        red[8 * W + wave] = pmax;
     }
     __syncthreads();
+    pmax = red[8 * W];
     bmax = red[4 * W];
     neg = (int)red[5 * W];
     trig = (int)red[6 * W];
@@ -417,11 +430,14 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
 #pragma unroll
     for (int w = 1; w < W; ++w) {
         bmax = fmax(bmax, red[4 * W + w]);
+        pmax = fmax(pmax, red[8 * W + w]);
         neg |= (int)red[5 * W + w];
         trig |= (int)red[6 * W + w];
         ragged |= (int)red[7 * W + w];
     }
     bmax = uniform(bmax);
+    red[9 * W + kKeepPf2Max] = pmax;
+    red[9 * W + kKeepGbMax] = kGyro * bmax;
     neg = uniform(neg);
     trig = uniform(trig);
     ragged = uniform(ragged);
@@ -691,35 +707,55 @@ template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
                                           const BlockInfo& info, long long prof_local, int block_in_prof,
-                                          int blocks_per_prof, int* item_next) {
+                                          int blocks_per_prof, int* item_next, const double* red) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63;
-    const int F = (int)a.n_freq;
-    const int C = sg.chunks;
-    const long long T = (long long)F * C;
+    const double* keep = kept_scalars<THREADS>(red);
+    const int F = uniform((int)a.n_freq);
+    const int C = uniform(sg.chunks);
+    const int T = F * C;                           // < 2^31: n_freq <= 2^20, chunks <= n_points / 256
     const double* mult = a.mult + sg.mult_off;
     const double2* pairs = a.pairs ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
+    const int first_item = block_in_prof * W, round_items = blocks_per_prof * W;
     // Items are handed out first come, first served.  The SIMD arbiter favours its older waves: with a
     // fixed share per wave, waves 0-3 of a workgroup were done at 70 % of its life (tools/wave_trace.py)
     // and their slots sat empty for the rest.  Which wave computes a pair does not change its value.
-    for (;;) {
-        int u = 0;
-        if (lane == 0) u = atomicAdd(item_next, 1);
-        u = uniform(u);
+    // Everything that steers this loop is wave-uniform and kept in SGPRs (uniform()), so that the
+    // compiler emits scalar branches and not exec-masked loops around the wave-level operations inside.
+    // Every lane takes part in the atomic (the compiler folds the 64 increments into one LDS add of 64
+    // and hands lane 0 the old value): no lane-divergent branch in this loop's control flow.
+    auto next_item = [&]() {
+        const int u = uniform(atomicAdd(item_next, 1)) >> 6;
         // this block's items: rounds of W, interleaved with the profile's other blocks
-        const long long t = (long long)(u / W) * blocks_per_prof * W + (long long)block_in_prof * W + (u % W);
-        if (t >= T) break;
-        const int f = (int)(t % F);
-        const int c = (int)(t / F);
+        return uniform((u / W) * round_items + first_item + (u % W));
+    };
+    for (int t = next_item(); t < T; t = next_item()) {
+        const int f = t % F;
+        const int c = t / F;
         double result = qnan();
         bool reflects = false;
         if (!info.bad) {
             const double f_hz = uniform(a.freq[f] * 1e6);      // :491
             const double f2 = uniform(f_hz * f_hz);            // f**2
-            double h;
-            reflects = reflection_height<MODE>(nodes, pf2, gb, info.K, f_hz, f2, lane, &h);
-            h = uniform(h);
+            double h = 0.0;
+            // Escapes for certain?  Division and addition are monotone, so the reference's X (O mode) or
+            // X + Y (X mode) at every level is <= the same expression of the two maxima: below 1 there, the
+            // running maximum never reaches 1 (:399) and the level scan can be skipped - it is most of the
+            // per-pair cost when n_points is small.  (K == 1 keeps the full path: np.interp's one-node quirk.)
+            int scan = 1;
+#ifndef PRHF_NO_ESCAPE_TEST
+            if (info.K > 1) {
+#pragma clang fp contract(off)
+                double ub = keep[kKeepPf2Max] / f2;
+                if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] / f_hz;
+                scan = uniform((int)!(ub < 1.0));
+            }
+#endif
+            if (scan) {
+                reflects = uniform((int)reflection_height<MODE>(nodes, pf2, gb, info.K, f_hz, f2, lane, &h)) != 0;
+                h = uniform(h);
+            }
             if (reflects) {
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
@@ -750,7 +786,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
         if (lane == 0) {
             if (C == 1) {
                 // :290-292: exact zero means every term was NaN -> NaN; then add min(alt)
-                const double vh = (reflects && result != 0.0) ? result + info.alt_min : qnan();
+                const double vh = (reflects && result != 0.0) ? result + keep[kKeepAltMin] : qnan();
                 a.out[sg.out_off + pair_base + f] = vh;
             } else {
                 a.partial[sg.partial_off + (pair_base + f) * C + c] = reflects ? result : qnan();
@@ -771,14 +807,14 @@ __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
     if (threadIdx.x == 0 && block_in_prof == 0) {
         if (info.bad) atomicOr(a.status, (unsigned)info.bad);
-        if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = info.alt_min;
+        if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
     }
     if (sg.mode == PRHF_KMODE_O)
         run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
-                                               blocks_per_prof, item_next);
+                                               blocks_per_prof, item_next, red);
     else
         run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
-                                               blocks_per_prof, item_next);
+                                               blocks_per_prof, item_next, red);
 }
 
 // TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
