@@ -581,6 +581,71 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     return __builtin_fma(fmax(mup, 0.0), g.y, acc);
 }
 
+// The fast tier's main loop over the whole wave-iterations of [first, full_end) - all of them that end
+// at or before full_end - 64: returns span * sum of mu' * (m_i+1 - m_i) (per lane).
+// Deliberately NOT inlined: inside the fused kernel ~100 wave-uniform values are live around this loop,
+// and whenever the register allocator ran out of SGPRs it parked the buffer descriptor in VGPR lanes and
+// paid 8 v_readlane per trip (seen three times while the surrounding code changed).  As a function the
+// loop keeps its dozen scalars in SGPRs whatever the caller looks like; the call costs ~100 cycles per pair.
+template <int MODE>
+__device__ __attribute__((noinline)) double lean_loop(unsigned nodes_lds, int K,
+                                                      const double2* __restrict__ pairs, int n_points, int first,
+                                                      int full_end, double span, double a0, double kj, double cX,
+                                                      double cY2) {
+#pragma clang fp contract(fast)
+    // arguments arrive in VGPRs: back to SGPRs.  The node table travels as its 32-bit LDS address (a
+    // generic pointer would turn every node read into a flat load).
+    typedef __attribute__((address_space(3))) const Node* LdsNodes;
+    const Node* nodes = (const Node*)(LdsNodes)(uintptr_t)(unsigned)uniform((int)nodes_lds);
+    K = uniform(K); n_points = uniform(n_points); first = uniform(first); full_end = uniform(full_end);
+    span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX); cY2 = uniform(cY2);
+    pairs = reinterpret_cast<const double2*>(
+        ((unsigned long long)(unsigned)uniform((int)((unsigned long long)pairs >> 32)) << 32) |
+        (unsigned)uniform((int)(unsigned long long)pairs));
+    const int lane = threadIdx.x & 63;
+    double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
+    asm volatile("" : "+v"(a0v));
+    // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
+    // SGPR, so the loop spends no vector instruction on addresses (and reads past the table
+    // would return 0 instead of faulting).
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double2*>(pairs), 0, n_points * (int)sizeof(double2), 0x00020000);
+#ifdef PRHF_PAIR_GLOBAL
+    auto grid_at = [&](int i) { return pairs[i + lane]; };
+#else
+    auto grid_at = [&](int i) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
+        double2 g;
+        __builtin_memcpy(&g, &v, sizeof g);
+        return g;
+    };
+#endif
+    double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
+    double2 g0 = grid_at(first);
+#if PRHF_LEAN_UNROLL == 2
+    // two wave-iterations per trip so that the prefetch registers swap roles without moves
+    for (; first + 192 <= full_end; first += 128) {
+        const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
+        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
+        g0 = grid_at(first + 128);
+        accm = lean_step<MODE>(nodes, K, g1, span, a0v, kj, cX, cY2, accm);
+    }
+    if (first + 128 <= full_end) {                     // odd wave-iteration left over
+        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
+        first += 64;
+    }
+#else
+    for (; first + 128 <= full_end; first += 64) {
+        const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
+        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
+        g0 = g1;
+    }
+#endif
+    return accm * span;                                    // :415: dh = (m_i+1 - m_i) * span
+}
+
 // ---------------------------------------------------------------------------------------
 // S7-S11 for grid points [i0, i1) of one pair; returns this wave's partial sum (all lanes).
 // The multiplier loads of iteration n+1 are issued before the arithmetic of iteration n.
@@ -612,47 +677,12 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
         // span < 0: left clamp, generic loop; kj <= K - 1 keeps the closed-form index inside the node table
         if (first + 128 <= full_end && span >= 0.0 && kj <= (double)(K - 1)) {
-            double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
-            asm volatile("" : "+v"(a0v));
-            // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
-            // SGPR, so the loop spends no vector instruction on addresses (and reads past the table
-            // would return 0 instead of faulting).
-            const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<double2*>(pairs), 0, n_points * (int)sizeof(double2), 0x00020000);
-#ifdef PRHF_PAIR_GLOBAL
-            auto grid_at = [&](int i) { return pairs[i + lane]; };
-#else
-            auto grid_at = [&](int i) {
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
-                double2 g;
-                __builtin_memcpy(&g, &v, sizeof g);
-                return g;
-            };
-#endif
-            double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
-            double2 g0 = grid_at(first);
-#if PRHF_LEAN_UNROLL == 2
-            // two wave-iterations per trip so that the prefetch registers swap roles without moves
-            for (; first + 192 <= full_end; first += 128) {
-                const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
-                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-                g0 = grid_at(first + 128);
-                accm = lean_step<MODE>(nodes, K, g1, span, a0v, kj, cX, cY2, accm);
-            }
-            if (first + 128 <= full_end) {                     // odd wave-iteration left over
-                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-                first += 64;
-            }
-#else
-            for (; first + 128 <= full_end; first += 64) {
-                const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
-                accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-                g0 = g1;
-            }
-#endif
-            acc = accm * span;                                 // :415: dh = (m_i+1 - m_i) * span
+            // the loop is a function of its own (not inlined): it gets a fresh scalar-register budget,
+            // see lean_loop
+            typedef __attribute__((address_space(3))) const Node* LdsNodes;
+            acc = lean_loop<MODE>((unsigned)(uintptr_t)(LdsNodes)nodes, K, pairs, n_points, first, full_end, span, a0,
+                                  kj, cX, cY2);
+            first += ((full_end - first - 64) / 64) * 64;      // what the loop consumed (first + 128 <= full_end)
         }
     }
     int i = first + lane;
