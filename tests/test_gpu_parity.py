@@ -260,3 +260,34 @@ def test_mixed_worklist_on_device_tensors(lib):
     assert out.is_cuda and out.shape == (24, g["freq"].size)
     assert np.array_equal(out.cpu().numpy(), host, equal_nan=True)
     assert np.all(np.isnan(host[14:20]))
+
+
+def test_cached_device_grids_alternate_without_going_stale(lib):
+    """GPU-resident calls reuse one device grid per n_points and tell the library it may keep the table it
+    derives from it (PRHF_FLAG_GRID_STABLE).  Alternating grid sizes, a mixed work list in between and a
+    host-buffer call must each get the table of their own grid."""
+    import torch
+    g = load_golden("g5_chapman64.npz")
+    dev = torch.device("cuda:0")
+    t = [torch.as_tensor(g[k], device=dev) for k in ("freq", "den", "bmag", "bpsi", "alt")]
+    h = [g[k] for k in ("freq", "den", "bmag", "bpsi", "alt")]
+    want = {n: lib.vertical_forward_operator(*h, "X", n) for n in (2000, 20000, 777)}
+    segs = [(0, 30, "X", 777), (30, 64, "X", 2000)]
+    want_mixed = lib.vertical_forward_operator_mixed(*h, segs)
+    for n in (2000, 20000, 2000, 777, 20000, 777):
+        got = lib.vertical_forward_operator(*t, "X", n).cpu().numpy()
+        assert np.array_equal(got, want[n], equal_nan=True), n
+        mixed = lib.vertical_forward_operator_mixed(*t, segs).cpu().numpy()
+        assert np.array_equal(mixed, want_mixed, equal_nan=True), n
+        assert np.array_equal(lib.vertical_forward_operator(*h, "X", n), want[n], equal_nan=True), n
+
+
+def test_flag_validation_of_the_grid_stable_bit():
+    """PRHF_FLAG_GRID_STABLE only makes sense for device pointers."""
+    from pyrayhf_amd import _native
+    ctx = _native.context(0)
+    one = np.ones(4)
+    out = np.empty(1)
+    rc = ctx.vfo_batch(one.ctypes.data, 1, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data,
+                       1, 4, 4, 0, one.ctypes.data, 4, 0, out.ctypes.data, _native.FLAG_GRID_STABLE)
+    assert rc == _native.EINVAL and "device pointers" in _native.last_error()
