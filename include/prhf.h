@@ -53,7 +53,9 @@ extern "C" {
 /* arithmetic tiers, prhf_ctx_set_math (see DESIGN.md "Arithmetic tiers") */
 #define PRHF_MATH_FAITHFUL 0  /* reference operation order, IEEE divide/sqrt, no contraction */
 #define PRHF_MATH_FAST     1  /* reduced algebra, rsqrt + Newton, contracted; X-mode error <= 1e-9 relative */
-#define PRHF_MATH_AUTO     2  /* per slice: faithful for O mode (ill conditioned), fast for X mode; the default */
+#define PRHF_MATH_AUTO     2  /* the default, per slice.  X mode: fast.  O mode (ill conditioned near X = 1): the
+                               * reference's operation order at every grid point with 1 - X <= 1e-4, the reduced
+                               * algebra where the order cannot matter; reproduces the reference to 1e-10 */
 
 typedef struct prhf_ctx prhf_ctx;
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
+constexpr double kWellConditioned = 1e-4;  // hybrid O mode reproduces the reference to 1e-10
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
@@ -189,6 +191,9 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.mode = u.mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
         s.n_points = u.n_points;
         s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
+        // AUTO, O mode: the reference's operation order where it decides the answer (1 - X <= 1e-4), the
+        // reduced algebra elsewhere; PRHF_MATH_FAITHFUL keeps the reference's order everywhere
+        s.well_conditioned = (c->math == PRHF_MATH_AUTO && s.tier == 0) ? kWellConditioned : HUGE_VAL;
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq, wg_slots);
         // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
@@ -199,7 +204,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // the lowest indices so that a mixed launch does not end on its longest workgroups.
     std::stable_sort(a.seg, a.seg + n_segs, [](const prhf::SegDev& x, const prhf::SegDev& y) {
         auto cost = [](const prhf::SegDev& s) {
-            return (double)s.n_points / s.chunks / s.blocks_per_prof * (s.tier == 0 ? 3.5 : 1.0);   // head workgroups
+            const double per_point = s.tier == 1 ? 1.0 : (s.well_conditioned < 1.0 ? 1.8 : 3.5);
+            return (double)s.n_points / s.chunks / s.blocks_per_prof * per_point;   // head workgroups
         };
         return cost(x) > cost(y);
     });

@@ -45,6 +45,9 @@ struct SegDev {
     // drains quickly: profiles [tail_prof, P) of the slice use tail_bpp blocks each (tail_prof = P: none).
     long long tail_prof;
     int tail_bpp;
+    // Faithful tier only: where 1 - X exceeds this at all 64 points of a wave-iteration the reduced
+    // algebra is used instead of the reference's operation order (+inf: never).
+    double well_conditioned;
 };
 
 struct KArgs {

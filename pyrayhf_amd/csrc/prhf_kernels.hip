@@ -489,11 +489,24 @@ __device__ __forceinline__ int guess_segment(const unsigned short* __restrict__ 
 // mu' at abscissa offset dz = z - alt_j >= 0 inside the segment that starts at node nd.
 template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_hz, double f2, double cX,
-                                            double cY2, bool poly_angle) {
+                                            double cY2, bool poly_angle, double well_conditioned) {
     double mu, mup;
     if (TIER == 0) {
 #pragma clang fp contract(off)
         const double den = nd.sden * dz + nd.den;      // numpy arr_interp: slope*(x - xp[j]) + fp[j]
+        if (!UNMAG) {
+            // Where 1 - X is not small at any of the wave's points, the operation order does not matter
+            // (both forms agree to 1e-12 there) and the reduced algebra - no divide, no sqrt - is used;
+            // near X = 1, where the reference's rounding decides the answer, its order is kept.
+            const double Xq = den * cX;
+            if (__all(1.0 - Xq > well_conditioned)) {
+#pragma clang fp contract(fast)
+                const double b = nd.sb * dz + nd.b;
+                const double sn = sin((nd.u1 * dz + nd.u0) * kDegToRad);
+                index_fast<MODE>(Xq, (b * b) * cY2, sn * sn, &mu, &mup);
+                return mup;
+            }
+        }
         const double fn = sqrt(den) * kPlasma;         // :96
         const double X = (fn * fn) / f2;               // :136
         if (UNMAG) {
@@ -655,7 +668,8 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                                                   const unsigned short* __restrict__ hint,
                                                   const BlockInfo& info, const double* __restrict__ mult,
                                                   const double2* __restrict__ pairs, int n_points, int i0,
-                                                  int i1, double f_hz, double f2, double h_refl, int lane) {
+                                                  int i1, double f_hz, double f2, double h_refl, int lane,
+                                                  double well_conditioned) {
     const int K = info.K;
     const double a0 = info.a0;
     const double span = uniform(h_refl - a0);      // :413 (critical_height - aalt[0])
@@ -723,7 +737,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         } else {
             dz = fmax(__builtin_fma(m0, span, nd.off), 0.0);       // 0: z below the first level, left value
         }
-        const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY2, poly_angle);
+        const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY2, poly_angle, well_conditioned);
         const double term = mup * dh;              // :288
         if (term == term) acc = acc + term;        // nansum
         i = inext;
@@ -741,6 +755,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63;
     const double* keep = kept_scalars<THREADS>(red);
+    const double wc = uniform(sg.well_conditioned);
     const int F = uniform((int)a.n_freq);
     const int C = uniform(sg.chunks);
     const int T = F * C;                           // < 2^31: n_freq <= 2^20, chunks <= n_points / 256
@@ -791,10 +806,10 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
                 if (info.unmag)
                     result = integrate_chunk<MODE, TIER, true>(nodes, hint, info, mult, pairs, sg.n_points, i0, i1,
-                                                               f_hz, f2, h, lane);
+                                                               f_hz, f2, h, lane, wc);
                 else
                     result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, sg.n_points, i0,
-                                                                i1, f_hz, f2, h, lane);
+                                                                i1, f_hz, f2, h, lane, wc);
             } else if (info.K == 1) {
                 // A one-level bottomside: np.interp with a single node returns that node even
                 // for the NaN abscissae of an escaping frequency (numpy arr_interp, lenxp == 1),
@@ -804,8 +819,8 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 if (c == C - 1) {
                     const bool poly = info.poly_angle != 0;
                     const double mup = info.unmag
-                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly)
-                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly);
+                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly, sg.well_conditioned)
+                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly, sg.well_conditioned);
                     term = mup * kBackoff;
                     if (!(term == term)) term = 0.0;
                 }

@@ -38,6 +38,9 @@ run("2: Day profile x 174, X/20000", f174, *day, "X", 20000, reps=20)
 alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
 run("3: 10000 Chapman x 174, O/200", f174, alt, den, bmag, bpsi, "O", 200)
 run("3 (fast tier): 10000 Chapman x 174, O/200", f174, alt, den, bmag, bpsi, "O", 200, math=library.MATH_FAST)
+run("3 (faithful everywhere): 10000 Chapman x 174, O/200", f174, alt, den, bmag, bpsi, "O", 200, math=library.MATH_FAITHFUL)
+run("3b: 2000 Chapman x 174, O/20000", f174, alt, den[:2000], bmag[:2000], bpsi[:2000], "O", 20000, reps=3)
+run("3b (faithful everywhere): 2000 Chapman x 174, O/20000", f174, alt, den[:2000], bmag[:2000], bpsi[:2000], "O", 20000, reps=2, math=library.MATH_FAITHFUL)
 alt, den, bmag, bpsi = synth.chapman_profiles(100000, 20260004, rows=slice(0, 12500))
 run("4 shard: 12500 Chapman x 256, X/20000", synth.sounder_frequencies(4), alt, den, bmag, bpsi, "X", 20000, reps=3)
 run("4 shard (faithful): 12500 Chapman x 256, X/20000", synth.sounder_frequencies(4), alt, den, bmag, bpsi, "X", 20000,
