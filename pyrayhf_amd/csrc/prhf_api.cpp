@@ -43,7 +43,7 @@ constexpr double kWellConditioned = 1e-4;  // hybrid O mode
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
-constexpr long long kMaxAlt = 1600;        // nodes + hints must fit 160 KiB of LDS
+constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
 struct DevBuf {
@@ -197,7 +197,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq, wg_slots);
         // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
-        want_pairs = want_pairs || (s.tier == 1 && u.n_points > 128 && u.prof_end > u.prof_begin);
+        want_pairs = want_pairs || ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points > 128 && u.prof_end > u.prof_begin);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
     // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup

@@ -15,13 +15,10 @@
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
 #endif
-#ifndef PRHF_LEAN_UNROLL
-#define PRHF_LEAN_UNROLL 2          // wave-iterations per trip of the fast tier's main loop
-#endif
 #define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
-#define PRHF_NODE_BYTES 80          // one staged bottomside level
+#define PRHF_NODE_BYTES 96          // one staged bottomside level
 #ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
 #endif

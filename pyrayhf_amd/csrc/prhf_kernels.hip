@@ -38,16 +38,18 @@ constexpr double kPolyAngle = 3e-4;                 // rad per segment below whi
 
 // One bottomside level = the left end of one np.interp segment [alt_j, alt_j+1): den, b are the
 // level values, sden, sb the np.interp slopes, and the abscissa is dz = z - alt_j.
-//   faithful tier: u0 = psi [deg], u1 = d(psi)/dz [deg/km]; dz is computed as the reference does.
-//   fast tier:     dz = m*span + off in one FMA, off = alt_0 - alt_j (z = m*span + alt_0, :413).
+//   reference-order arithmetic: psi [deg], spsi = d(psi)/dz [deg/km]; dz is computed as the reference does.
+//   reduced arithmetic:         dz = m*span + off in one FMA, off = alt_0 - alt_j (z = m*span + alt_0, :413).
 //                  Segment turning psi by < kPolyAngle: sin^2(psi) = u0 + dz*(u1 + dz*(u2 + dz*u3));
 //                  other segments: u0 = psi_j [rad], u1 = d(psi)/dz [rad/km], u3 = NaN (the flag).
+// Both sets are staged in both tiers: the faithful tier's default mode uses the reduced arithmetic wherever
+// 1 - X is not small.
 // Everything is anchored at the LEFT level on purpose: below a steep layer den_j can be 0 (or
 // 1e-15 of den_j+1) and den_j + sden*dz keeps its relative accuracy there, which an expansion
 // about the segment centre would not (a density of -1e-6 m^-3 is enough to flip mu > 1, :238).
 // off sits next to alt so that the main loop reads off..u3 as 8 + 4 x 16 bytes.
 struct __attribute__((aligned(16))) Node {
-    double alt, off, den, sden, b, sb, u0, u1, u2, u3;
+    double alt, off, den, sden, b, sb, u0, u1, u2, u3, psi, spsi;
 };
 static_assert(sizeof(Node) == PRHF_NODE_BYTES, "node size");
 
@@ -364,7 +366,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
             nd.alt = __builtin_inf();
-            nd.den = nd.sden = nd.b = nd.sb = nd.u0 = nd.u1 = nd.u2 = nd.u3 = nd.off = 0.0;
+            nd.den = nd.sden = nd.b = nd.sb = nd.u0 = nd.u1 = nd.u2 = nd.u3 = nd.off = nd.psi = nd.spsi = 0.0;
             nodes[k] = nd;
             continue;
         }
@@ -382,24 +384,22 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         } else {
             nd.sden = 0.0; nd.sb = 0.0;
         }
-        if (TIER == 0) {
-            nd.u0 = p; nd.u1 = spsi; nd.u2 = 0.0; nd.u3 = 0.0;
-        } else {
-            nd.off = alt[0] - a;
-            if (turn < kPolyAngle) {
-                // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
-                const double r = spsi * kDegToRad;
-                double sp, cp;
-                sincos(p * kDegToRad, &sp, &cp);
-                const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
-                nd.u0 = sp * sp;
-                nd.u1 = s2p * r;
-                nd.u2 = c2p * (r * r);
-                nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
-            } else {                               // this segment turns the field too far for the cubic
-                nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
-                trig = 1;
-            }
+        nd.psi = p;
+        nd.spsi = spsi;
+        nd.off = alt[0] - a;
+        if (turn < kPolyAngle) {
+            // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
+            const double r = spsi * kDegToRad;
+            double sp, cp;
+            sincos(p * kDegToRad, &sp, &cp);
+            const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
+            nd.u0 = sp * sp;
+            nd.u1 = s2p * r;
+            nd.u2 = c2p * (r * r);
+            nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
+        } else {                                   // this segment turns the field too far for the cubic
+            nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
+            trig = 1;
         }
         nodes[k] = nd;
         const double fn = sqrt(d) * kPlasma;       // :96
@@ -502,7 +502,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             if (__all(1.0 - Xq > well_conditioned)) {
 #pragma clang fp contract(fast)
                 const double b = nd.sb * dz + nd.b;
-                const double sn = sin((nd.u1 * dz + nd.u0) * kDegToRad);
+                const double sn = sin((nd.spsi * dz + nd.psi) * kDegToRad);
                 index_fast<MODE>(Xq, (b * b) * cY2, sn * sn, &mu, &mup);
                 return mup;
             }
@@ -513,7 +513,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             index_unmagnetised(X, &mu, &mup);
         } else {
             const double b = nd.sb * dz + nd.b;
-            const double psi = nd.u1 * dz + nd.u0;
+            const double psi = nd.spsi * dz + nd.psi;
             const double Y = (kGyro * b) / f_hz;       // :157
             index_faithful<MODE>(X, Y, psi, &mu, &mup);
         }
@@ -543,9 +543,12 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // on the sin^2 cubic, span >= 0, not the last grid point).  g = (m_i, m_i+1 - m_i) from the pair
 // table; returns acc + mu' * (m_i+1 - m_i), or acc where the reference's term is NaN (:233, :238,
 // :288) - the caller multiplies the sum by span once (:415).
-template <int MODE>
+// CHECK: also report (in `viol`, a lane mask) the points whose X is not below x_max - the caller of the
+// faithful tier's default mode only accepts wave-iterations where the reduced arithmetic is safe.
+template <int MODE, bool CHECK>
 __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
-                                            double a0, double kj, double cX, double cY2, double acc) {
+                                            double a0, double kj, double cX, double cY2, double acc,
+                                            double x_max, unsigned long long& viol) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
@@ -582,7 +585,9 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     const double b = bb.y * x + bb.x;
     const double S2 = ua.x + x * (ua.y + x * (ub.x + x * ub.y));
     double mu, mup, q;
-    index_fast_core<MODE, true>(den * cX, (b * b) * cY2, S2, &mu, &mup, &q);
+    const double X = den * cX;
+    if (CHECK) viol |= __ballot(!(X < x_max));
+    index_fast_core<MODE, true>(X, (b * b) * cY2, S2, &mu, &mup, &q);
     // Validity (:233, :238) on this path, where 0 <= X and X (+ Y) < 1 hold at every level below the
     // reflection height and therefore between the levels (all three interpolants are linear):
     //   D > 0:  O mode D = (1-X) - h + beta >= 1-X;  X mode D > 0 <=> (1-X)(1 - YL^2) > YT^2, which
@@ -600,18 +605,26 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
 // and whenever the register allocator ran out of SGPRs it parked the buffer descriptor in VGPR lanes and
 // paid 8 v_readlane per trip (seen three times while the surrounding code changed).  As a function the
 // loop keeps its dozen scalars in SGPRs whatever the caller looks like; the call costs ~100 cycles per pair.
-template <int MODE>
-__device__ __attribute__((noinline)) double lean_loop(unsigned nodes_lds, int K,
-                                                      const double2* __restrict__ pairs, int n_points, int first,
-                                                      int full_end, double span, double a0, double kj, double cX,
-                                                      double cY2) {
+struct LeanResult {
+    double acc;     // span * sum of mu' * (m_i+1 - m_i), per lane
+    int first;      // first grid point not consumed
+};
+
+// CHECK (faithful tier, default mode): stop in front of the first trip that holds a point with
+// 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
+template <int MODE, bool CHECK>
+__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, int K,
+                                                          const double2* __restrict__ pairs, int first,
+                                                          int full_end, double span, double a0, double kj,
+                                                          double cX, double cY2, double well_conditioned) {
 #pragma clang fp contract(fast)
     // arguments arrive in VGPRs: back to SGPRs.  The node table travels as its 32-bit LDS address (a
     // generic pointer would turn every node read into a flat load).
     typedef __attribute__((address_space(3))) const Node* LdsNodes;
     const Node* nodes = (const Node*)(LdsNodes)(uintptr_t)(unsigned)uniform((int)nodes_lds);
-    K = uniform(K); n_points = uniform(n_points); first = uniform(first); full_end = uniform(full_end);
+    K = uniform(K); first = uniform(first); full_end = uniform(full_end);
     span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX); cY2 = uniform(cY2);
+    const double x_max = CHECK ? uniform(1.0 - well_conditioned) : 0.0;
     pairs = reinterpret_cast<const double2*>(
         ((unsigned long long)(unsigned)uniform((int)((unsigned long long)pairs >> 32)) << 32) |
         (unsigned)uniform((int)(unsigned long long)pairs));
@@ -619,14 +632,11 @@ __device__ __attribute__((noinline)) double lean_loop(unsigned nodes_lds, int K,
     double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
     asm volatile("" : "+v"(a0v));
     // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
-    // SGPR, so the loop spends no vector instruction on addresses (and reads past the table
-    // would return 0 instead of faulting).
+    // SGPR, so the loop spends no vector instruction on addresses (indices are in bounds by
+    // construction: the last load of a trip ends before full_end <= n_points - 1).
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double2*>(pairs), 0, n_points * (int)sizeof(double2), 0x00020000);
-#ifdef PRHF_PAIR_GLOBAL
-    auto grid_at = [&](int i) { return pairs[i + lane]; };
-#else
+        const_cast<double2*>(pairs), 0, 0x7fffffff, 0x00020000);
     auto grid_at = [&](int i) {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
@@ -634,29 +644,36 @@ __device__ __attribute__((noinline)) double lean_loop(unsigned nodes_lds, int K,
         __builtin_memcpy(&g, &v, sizeof g);
         return g;
     };
-#endif
     double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
+    unsigned long long viol = 0;
     double2 g0 = grid_at(first);
-#if PRHF_LEAN_UNROLL == 2
     // two wave-iterations per trip so that the prefetch registers swap roles without moves
     for (; first + 192 <= full_end; first += 128) {
         const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
-        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-        g0 = grid_at(first + 128);
-        accm = lean_step<MODE>(nodes, K, g1, span, a0v, kj, cX, cY2, accm);
+        if (!CHECK) {
+            accm = lean_step<MODE, false>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+            g0 = grid_at(first + 128);
+            accm = lean_step<MODE, false>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol);
+        } else {
+            const double a1 = lean_step<MODE, true>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+            const double2 g2 = grid_at(first + 128);
+            const double a2 = lean_step<MODE, true>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol);
+            if (viol) break;                           // neither half of this trip counts
+            accm = a2;
+            g0 = g2;
+        }
     }
-    if (first + 128 <= full_end) {                     // odd wave-iteration left over
-        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-        first += 64;
+    if (!(CHECK && viol) && first + 128 <= full_end) { // odd wave-iteration left over
+        const double a1 = lean_step<MODE, CHECK>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+        if (!(CHECK && viol)) {
+            accm = a1;
+            first += 64;
+        }
     }
-#else
-    for (; first + 128 <= full_end; first += 64) {
-        const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
-        accm = lean_step<MODE>(nodes, K, g0, span, a0v, kj, cX, cY2, accm);
-        g0 = g1;
-    }
-#endif
-    return accm * span;                                    // :415: dh = (m_i+1 - m_i) * span
+    LeanResult r;
+    r.acc = accm * span;                               // :415: dh = (m_i+1 - m_i) * span
+    r.first = first;
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -680,11 +697,13 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     const int last = n_points - 1;
     double acc = 0.0;
     int first = i0;                                // first grid point of the next wave-iteration
-    if (TIER == 1 && !UNMAG && poly_angle && info.uniform && pairs != nullptr) {
+    if (!UNMAG && poly_angle && info.uniform && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
         // Lean main loop of the common case (uniform altitude grid, slowly turning field):
         // whole wave-iterations that neither touch the last grid point nor need lane masks,
         // so there is no index clamping, no exec masking and the loop control is scalar.
-        // The wave-iterations that remain (at most three) go through the generic loop below.
+        // The wave-iterations that remain go through the generic loop below: at most three in the
+        // fast tier; in the faithful tier's default mode also everything from the first trip on that
+        // holds a point with 1 - X <= well_conditioned.
 #pragma clang fp contract(fast)
         first = uniform(first);
         const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
@@ -694,9 +713,10 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             // the loop is a function of its own (not inlined): it gets a fresh scalar-register budget,
             // see lean_loop
             typedef __attribute__((address_space(3))) const Node* LdsNodes;
-            acc = lean_loop<MODE>((unsigned)(uintptr_t)(LdsNodes)nodes, K, pairs, n_points, first, full_end, span, a0,
-                                  kj, cX, cY2);
-            first += ((full_end - first - 64) / 64) * 64;      // what the loop consumed (first + 128 <= full_end)
+            const LeanResult r = lean_loop<MODE, TIER == 0>((unsigned)(uintptr_t)(LdsNodes)nodes, K, pairs, first,
+                                                           full_end, span, a0, kj, cX, cY2, well_conditioned);
+            acc = r.acc;
+            first = uniform(r.first);
         }
     }
     int i = first + lane;
@@ -1165,7 +1185,7 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
             if (dz < 0.0) dz = 0.0;
             d = nd.sden * dz + nd.den;                                       // :424-426
             b = nd.sb * dz + nd.b;
-            p = nd.u1 * dz + nd.u0;
+            p = nd.spsi * dz + nd.psi;
         }
         a.out_freq[row + i] = f_hz;
         a.out_den[row + i] = d;
