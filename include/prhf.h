@@ -102,6 +102,7 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *   multiplier  (n_points) stretched unit grid, smooth_nonuniform_grid(0,1,n_points,10.)
  *               (library.py:296-321, :361-364) computed by the host in float64
  *   vh_out      (n_prof, n_freq) row-major
+ * Limits: n_alt <= 1400 (a profile's bottomside is held in LDS), n_freq <= 2^20, n_points >= 1.
  */
 int prhf_vfo_batch_f64(prhf_ctx* ctx,
                        const double* freq_mhz, int64_t n_freq,
