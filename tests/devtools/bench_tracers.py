@@ -3,7 +3,7 @@
 host core.  The reference quotes 1.4 ms (flat) and 2.3 ms (spherical) per ray on an unspecified laptop
 (docs/tutorials/Example_PyRayHF_{Cartesian,Spherical}_Snells.ipynb, cell 1 outputs)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pyrayhf_amd import tracers, synth, _native
 from oracle import snell_numpy as sn
