@@ -548,23 +548,26 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 template <int MODE, bool CHECK>
 __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
                                             double a0, double kj, double cX, double cY2, double acc,
-                                            double x_max, unsigned long long& viol) {
+                                            double x_max, unsigned long long& viol, unsigned nodes_v) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
-    // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here
-#ifdef PRHF_LEAN_CLAMP
-    int j = (int)min((unsigned)(int)(m0 * kj), (unsigned)(K - 1));
-#else
+    // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here.  (A float
+    // "magic number" add cannot replace the conversion: it rounds to nearest, and the interpolants are
+    // anchored at the level BELOW the point.)
     int j = (int)(m0 * kj);
-#endif
-    const char* pn = static_cast<const char*>(__builtin_assume_aligned(
-        reinterpret_cast<const char*>(nodes) + __umul24((unsigned)j, (unsigned)sizeof(Node)), 16));
-    double off = *reinterpret_cast<const double*>(pn + 8);
-    double2 dd = *reinterpret_cast<const double2*>(pn + 16);       // den, sden
-    double2 bb = *reinterpret_cast<const double2*>(pn + 32);       // b, sb
-    double2 ua = *reinterpret_cast<const double2*>(pn + 48);       // u0, u1
-    double2 ub = *reinterpret_cast<const double2*>(pn + 64);       // u2, u3
+    typedef __attribute__((address_space(3))) const char* LdsBytes;
+    typedef __attribute__((address_space(3))) const double* LdsDouble;
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const vec2* LdsVec2;
+    const LdsBytes pn = (LdsBytes)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
+    double off = *(LdsDouble)(pn + 8);
+    const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48),
+               r_ub = *(LdsVec2)(pn + 64);
+    double2 dd = make_double2(r_dd.x, r_dd.y);                     // den, sden
+    double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
+    double2 ua = make_double2(r_ua.x, r_ua.y);                     // u0, u1
+    double2 ub = make_double2(r_ub.x, r_ub.y);                     // u2, u3
     // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
     asm volatile("" :: "v"(dd.x), "v"(dd.y), "v"(bb.x), "v"(bb.y), "v"(ua.x), "v"(ua.y), "v"(ub.x), "v"(ub.y));
     double x = __builtin_fma(m0, span, off);                   // z - alt_j with z = m*span + a0 (:413)
@@ -629,8 +632,9 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, in
         ((unsigned long long)(unsigned)uniform((int)((unsigned long long)pairs >> 32)) << 32) |
         (unsigned)uniform((int)(unsigned long long)pairs));
     const int lane = threadIdx.x & 63;
-    double a0v = a0;                                   // a VGPR copy: v_fma takes one SGPR operand
-    asm volatile("" : "+v"(a0v));
+    double a0v = a0;                                   // VGPR copies: v_fma / v_mad take one SGPR operand
+    unsigned nodes_v = (unsigned)(uintptr_t)(LdsNodes)nodes;
+    asm volatile("" : "+v"(a0v), "+v"(nodes_v));
     // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
     // SGPR, so the loop spends no vector instruction on addresses (indices are in bounds by
     // construction: the last load of a trip ends before full_end <= n_points - 1).
@@ -651,20 +655,20 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, in
     for (; first + 192 <= full_end; first += 128) {
         const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
         if (!CHECK) {
-            accm = lean_step<MODE, false>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+            accm = lean_step<MODE, false>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol);
+            accm = lean_step<MODE, false>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
         } else {
-            const double a1 = lean_step<MODE, true>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+            const double a1 = lean_step<MODE, true>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol);
+            const double a2 = lean_step<MODE, true>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v);
             if (viol) break;                           // neither half of this trip counts
             accm = a2;
             g0 = g2;
         }
     }
     if (!(CHECK && viol) && first + 128 <= full_end) { // odd wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol);
+        const double a1 = lean_step<MODE, CHECK>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
