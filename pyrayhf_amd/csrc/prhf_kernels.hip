@@ -35,6 +35,7 @@ constexpr double kDegToRad = 0.017453292519943295;  // numpy deg2rad multiplies 
 constexpr double kUnmagTol = 1e-12;                 // library.py:163
 constexpr double kLightKmS = 299792.458;            // library.py:70
 constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
+constexpr double kQuadAngle = 4e-5;                 // ... and below which its economised quadratic errs < 1.4e-15
 
 // One bottomside level = the left end of one np.interp segment [alt_j, alt_j+1): den, b are the
 // level values, sden, sb the np.interp slopes, and the abscissa is dz = z - alt_j.
@@ -271,7 +272,7 @@ struct BlockInfo {
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
-    int poly_angle;   // fast tier: sin^2(psi) cubic per segment is valid
+    int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0); 0: some use sin()
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
     double inv_step;  // 1 / level spacing (uniform grids)
@@ -361,7 +362,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
     double bmax = 0.0, pmax = 0.0;
-    int neg = 0, ragged = 0, trig = 0;
+    int neg = 0, ragged = 0, trig = 0, cubic = 0;
     for (int k = tid; k <= K; k += THREADS) {
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
@@ -397,6 +398,17 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             nd.u1 = s2p * r;
             nd.u2 = c2p * (r * r);
             nd.u3 = (-2.0 / 3.0) * s2p * (r * r * r);
+            if (turn < kQuadAngle) {
+                // Chebyshev economisation on [0, L]: x^3 ~ (3L/2) x^2 - (9L^2/16) x + L^3/32, error
+                // |u3| L^3 / 32 <= turn^3 / 48: the main loop then evaluates one FMA less per point
+                const double L = (k + 1 < K) ? alt[k + 1] - a : 0.0;
+                nd.u0 = nd.u0 + nd.u3 * (L * L * L) * (1.0 / 32.0);
+                nd.u1 = nd.u1 - nd.u3 * (L * L) * (9.0 / 16.0);
+                nd.u2 = nd.u2 + nd.u3 * L * 1.5;
+                nd.u3 = 0.0;
+            } else {
+                cubic = 1;
+            }
         } else {                                   // this segment turns the field too far for the cubic
             nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
             trig = 1;
@@ -413,7 +425,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     pmax = wave_max(pmax);
     neg = __any(neg) ? 1 : 0;
     ragged = __any(ragged) ? 1 : 0;
-    trig = __any(trig) ? 1 : 0;
+    trig = __any(trig) ? 1 : (__any(cubic) ? 2 : 0);   // 1: some segment needs sin(), 2: some segment keeps its cubic
     if (lane == 0) {
         red[4 * W + wave] = bmax;
         red[5 * W + wave] = (double)neg;
@@ -432,7 +444,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         bmax = fmax(bmax, red[4 * W + w]);
         pmax = fmax(pmax, red[8 * W + w]);
         neg |= (int)red[5 * W + w];
-        trig |= (int)red[6 * W + w];
+        trig = (trig == 1 || (int)red[6 * W + w] == 1) ? 1 : (trig | (int)red[6 * W + w]);
         ragged |= (int)red[7 * W + w];
     }
     bmax = uniform(bmax);
@@ -446,7 +458,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
     info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    info.poly_angle = trig ? 0 : 1;                // every segment uses the sin^2 cubic
+    info.poly_angle = trig == 1 ? 0 : (trig == 2 ? 1 : 2);
     // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
     const double a0 = uniform(nodes[0].alt);
     const double span = uniform(nodes[K - 1].alt) - a0;
@@ -545,7 +557,8 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // :288) - the caller multiplies the sum by span once (:415).
 // CHECK: also report (in `viol`, a lane mask) the points whose X is not below x_max - the caller of the
 // faithful tier's default mode only accepts wave-iterations where the reduced arithmetic is safe.
-template <int MODE, bool CHECK>
+// QUAD: every segment of the profile carries the economised quadratic (u3 = 0, not read).
+template <int MODE, bool CHECK, bool QUAD>
 __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
                                             double a0, double kj, double cX, double cY2, double acc,
                                             double x_max, unsigned long long& viol, unsigned nodes_v) {
@@ -562,14 +575,17 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     typedef __attribute__((address_space(3))) const vec2* LdsVec2;
     const LdsBytes pn = (LdsBytes)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
     double off = *(LdsDouble)(pn + 8);
-    const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48),
-               r_ub = *(LdsVec2)(pn + 64);
+    const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48);
+    vec2 r_ub;
+    if (QUAD) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
+    else r_ub = *(LdsVec2)(pn + 64);
     double2 dd = make_double2(r_dd.x, r_dd.y);                     // den, sden
     double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
     double2 ua = make_double2(r_ua.x, r_ua.y);                     // u0, u1
     double2 ub = make_double2(r_ub.x, r_ub.y);                     // u2, u3
     // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
-    asm volatile("" :: "v"(dd.x), "v"(dd.y), "v"(bb.x), "v"(bb.y), "v"(ua.x), "v"(ua.y), "v"(ub.x), "v"(ub.y));
+    asm volatile("" :: "v"(dd.x), "v"(dd.y), "v"(bb.x), "v"(bb.y), "v"(ua.x), "v"(ua.y), "v"(ub.x));
+    if (!QUAD) asm volatile("" :: "v"(ub.y));
     double x = __builtin_fma(m0, span, off);                   // z - alt_j with z = m*span + a0 (:413)
     // The closed-form index can miss by one where z rounds onto a level.  One segment too low is
     // harmless (a linear piece evaluated 1e-13 km past its end); one too high would extrapolate to
@@ -586,7 +602,7 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     }
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
-    const double S2 = ua.x + x * (ua.y + x * (ub.x + x * ub.y));
+    const double S2 = QUAD ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y));
     double mu, mup, q;
     const double X = den * cX;
     if (CHECK) viol |= __ballot(!(X < x_max));
@@ -615,7 +631,7 @@ struct LeanResult {
 
 // CHECK (faithful tier, default mode): stop in front of the first trip that holds a point with
 // 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
-template <int MODE, bool CHECK>
+template <int MODE, bool CHECK, bool QUAD>
 __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, int K,
                                                           const double2* __restrict__ pairs, int first,
                                                           int full_end, double span, double a0, double kj,
@@ -655,20 +671,20 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, in
     for (; first + 192 <= full_end; first += 128) {
         const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
         if (!CHECK) {
-            accm = lean_step<MODE, false>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            accm = lean_step<MODE, false, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            accm = lean_step<MODE, false, QUAD>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
         } else {
-            const double a1 = lean_step<MODE, true>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            const double a1 = lean_step<MODE, true, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v);
+            const double a2 = lean_step<MODE, true, QUAD>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v);
             if (viol) break;                           // neither half of this trip counts
             accm = a2;
             g0 = g2;
         }
     }
     if (!(CHECK && viol) && first + 128 <= full_end) { // odd wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+        const double a1 = lean_step<MODE, CHECK, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
@@ -717,8 +733,12 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             // the loop is a function of its own (not inlined): it gets a fresh scalar-register budget,
             // see lean_loop
             typedef __attribute__((address_space(3))) const Node* LdsNodes;
-            const LeanResult r = lean_loop<MODE, TIER == 0>((unsigned)(uintptr_t)(LdsNodes)nodes, K, pairs, first,
-                                                           full_end, span, a0, kj, cX, cY2, well_conditioned);
+            const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
+            const LeanResult r = (info.poly_angle == 2)
+                ? lean_loop<MODE, TIER == 0, true>(nodes_lds, K, pairs, first, full_end, span, a0, kj, cX, cY2,
+                                                   well_conditioned)
+                : lean_loop<MODE, TIER == 0, false>(nodes_lds, K, pairs, first, full_end, span, a0, kj, cX, cY2,
+                                                    well_conditioned);
             acc = r.acc;
             first = uniform(r.first);
         }
