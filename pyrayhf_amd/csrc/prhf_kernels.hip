@@ -558,10 +558,13 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // CHECK: also report (in `viol`, a lane mask) the points whose X is not below x_max - the caller of the
 // faithful tier's default mode only accepts wave-iterations where the reduced arithmetic is safe.
 // QUAD: every segment of the profile carries the economised quadratic (u3 = 0, not read).
-template <int MODE, bool CHECK, bool QUAD>
+// HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
+// (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
+template <int MODE, bool CHECK, bool QUAD, bool HINT>
 __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
                                             double a0, double kj, double cX, double cY2, double acc,
-                                            double x_max, unsigned long long& viol, unsigned nodes_v) {
+                                            double x_max, unsigned long long& viol, unsigned nodes_v,
+                                            unsigned hint_v) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
@@ -573,6 +576,20 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     typedef __attribute__((address_space(3))) const double* LdsDouble;
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const vec2* LdsVec2;
+    if (HINT) {
+        // j is a bucket (< kHintBuckets: m <= 1 and kj < kHintBuckets, checked by the caller)
+        typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
+        j = *(LdsU16)(uintptr_t)(hint_v + 2u * (unsigned)j);
+        const double z = __builtin_fma(m0, span, a0);
+        // np.interp's segment: alt[j] <= z < alt[j+1]; level K is a +inf sentinel, so the walk stops by itself
+        double above = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)(j + 1), (unsigned)sizeof(Node)));
+        while (__any(z >= above)) {
+            if (z >= above) {
+                ++j;
+                above = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)(j + 1), (unsigned)sizeof(Node)));
+            }
+        }
+    }
     const LdsBytes pn = (LdsBytes)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
     double off = *(LdsDouble)(pn + 8);
     const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48);
@@ -591,7 +608,9 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     // harmless (a linear piece evaluated 1e-13 km past its end); one too high would extrapolate to
     // the LEFT of level j, where a zero density turns negative: that side restores np.interp's
     // exact segment alt[j] <= z < alt[j+1].
-    if (__builtin_expect(__any(x < 0.0), 0)) {
+    if (HINT) {
+        x = fmax(x, 0.0);                                      // alt[j] <= z holds; this only absorbs rounding
+    } else if (__builtin_expect(__any(x < 0.0), 0)) {
         const double z = __builtin_fma(m0, span, a0);
         while (j > 0 && z < nodes[j].alt) --j;
         while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
@@ -631,8 +650,8 @@ struct LeanResult {
 
 // CHECK (faithful tier, default mode): stop in front of the first trip that holds a point with
 // 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
-template <int MODE, bool CHECK, bool QUAD>
-__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, int K,
+template <int MODE, bool CHECK, bool QUAD, bool HINT>
+__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds, int K,
                                                           const double2* __restrict__ pairs, int first,
                                                           int full_end, double span, double a0, double kj,
                                                           double cX, double cY2, double well_conditioned) {
@@ -650,7 +669,8 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, in
     const int lane = threadIdx.x & 63;
     double a0v = a0;                                   // VGPR copies: v_fma / v_mad take one SGPR operand
     unsigned nodes_v = (unsigned)(uintptr_t)(LdsNodes)nodes;
-    asm volatile("" : "+v"(a0v), "+v"(nodes_v));
+    unsigned hint_v = (unsigned)uniform((int)hint_lds);
+    asm volatile("" : "+v"(a0v), "+v"(nodes_v), "+v"(hint_v));
     // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
     // SGPR, so the loop spends no vector instruction on addresses (indices are in bounds by
     // construction: the last load of a trip ends before full_end <= n_points - 1).
@@ -671,20 +691,20 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, in
     for (; first + 192 <= full_end; first += 128) {
         const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
         if (!CHECK) {
-            accm = lean_step<MODE, false, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            accm = lean_step<MODE, false, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, QUAD>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            accm = lean_step<MODE, false, QUAD, HINT>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
         } else {
-            const double a1 = lean_step<MODE, true, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+            const double a1 = lean_step<MODE, true, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, QUAD>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v);
+            const double a2 = lean_step<MODE, true, QUAD, HINT>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v, hint_v);
             if (viol) break;                           // neither half of this trip counts
             accm = a2;
             g0 = g2;
         }
     }
     if (!(CHECK && viol) && first + 128 <= full_end) { // odd wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, QUAD>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v);
+        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
@@ -717,28 +737,37 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     const int last = n_points - 1;
     double acc = 0.0;
     int first = i0;                                // first grid point of the next wave-iteration
-    if (!UNMAG && poly_angle && info.uniform && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
-        // Lean main loop of the common case (uniform altitude grid, slowly turning field):
-        // whole wave-iterations that neither touch the last grid point nor need lane masks,
-        // so there is no index clamping, no exec masking and the loop control is scalar.
+    if (!UNMAG && poly_angle && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
+        // Lean main loop of the common case (slowly turning field; uniform altitude grid, or any grid
+        // through the hint table): whole wave-iterations that neither touch the last grid point nor need
+        // lane masks, so there is no index clamping, no exec masking and the loop control is scalar.
         // The wave-iterations that remain go through the generic loop below: at most three in the
         // fast tier; in the faithful tier's default mode also everything from the first trip on that
         // holds a point with 1 - X <= well_conditioned.
 #pragma clang fp contract(fast)
         first = uniform(first);
         const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
-        const double kj = uniform(span * info.inv_step);       // (z - a0) / step = m * kj
-        // span < 0: left clamp, generic loop; kj <= K - 1 keeps the closed-form index inside the node table
-        if (first + 128 <= full_end && span >= 0.0 && kj <= (double)(K - 1)) {
+        // index scale: (z - a0) / step = m * kj on a uniform grid, hint buckets per unit of m otherwise
+        const bool by_hint = !info.uniform;
+        // (the bucket scale is biased low by 1e-11: rounding must never select the bucket ABOVE the point,
+        // whose hinted level could lie above it too - one bucket too low only lengthens the walk up)
+        const double kj = uniform(by_hint ? span * info.inv_w * (1.0 - 1e-11) : span * info.inv_step);
+        // span < 0: left clamp, generic loop; the bound on kj keeps the closed-form index inside its table
+        const bool in_table = by_hint ? (kj < (double)kHintBuckets && info.inv_w > 0.0) : (kj <= (double)(K - 1));
+        if (first + 128 <= full_end && span >= 0.0 && in_table) {
             // the loop is a function of its own (not inlined): it gets a fresh scalar-register budget,
             // see lean_loop
             typedef __attribute__((address_space(3))) const Node* LdsNodes;
+            typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
             const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
-            const LeanResult r = (info.poly_angle == 2)
-                ? lean_loop<MODE, TIER == 0, true>(nodes_lds, K, pairs, first, full_end, span, a0, kj, cX, cY2,
-                                                   well_conditioned)
-                : lean_loop<MODE, TIER == 0, false>(nodes_lds, K, pairs, first, full_end, span, a0, kj, cX, cY2,
-                                                    well_conditioned);
+            const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
+            const bool quad = info.poly_angle == 2;
+            LeanResult r;
+#define PRHF_LEAN(Q, H) lean_loop<MODE, TIER == 0, Q, H>(nodes_lds, hint_lds, K, pairs, first, full_end, span, a0, \
+                                                           kj, cX, cY2, well_conditioned)
+            if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
+            else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
+#undef PRHF_LEAN
             acc = r.acc;
             first = uniform(r.first);
         }
