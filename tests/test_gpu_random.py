@@ -74,3 +74,34 @@ def test_random_problems_against_c_oracle(seed):
                         assert np.median(err[ok]) <= 1e-6, (seed, tier, n_points, np.median(err[ok]))
                 checked += 1
     assert checked > 100
+
+
+def test_non_uniform_grid_at_full_resolution():
+    """The main loop with its segment index from the hint table: Chapman layers sampled on a jittered altitude
+    grid (and, once more, on a grid that is uniform only to 1e-10), n_points = 20000, against the C oracle."""
+    from oracle import vfo_c
+    from pyrayhf_amd import library, synth
+    if not vfo_c.available():
+        pytest.skip("oracle/libvfo_oracle.so not built")
+    rng = np.random.default_rng(77)
+    freq = synth.sounder_frequencies(4)[::3]
+    base = np.arange(80.0, 700.0, 1.0)
+    for alt in (80.0 + np.concatenate([[0.0], np.cumsum(rng.uniform(0.4, 1.8, base.size - 1))]),
+                base * (1.0 + 1e-10 * rng.standard_normal(base.size))):
+        hm = rng.uniform(220.0, 420.0, (24, 1)); h = rng.uniform(35.0, 70.0, (24, 1))
+        nm = 10.0 ** rng.uniform(11.3, 12.5, (24, 1))
+        z = (alt[None, :] - hm) / h
+        den = nm * np.exp(0.5 * (1.0 - z - np.exp(-z))) + 2e10 * np.exp(-((alt[None, :] - 110.0) / 9.0) ** 2)
+        bmag = rng.uniform(2.2e-5, 6e-5, (24, 1)) * ((6371.0 + 80.0) / (6371.0 + alt[None, :])) ** 3
+        bpsi = rng.uniform(0.0, 89.0, (24, 1)) + 0.001 * (alt[None, :] - 80.0)
+        want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", 20000)
+        got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 20000)
+        assert_masks(got, want)
+        err, ok = rel_err(got, want)
+        assert ok.sum() > 500 and err.max() <= 1e-9, err.max()
+        want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", 2000)
+        got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 2000)
+        assert_masks(got, want)
+        err, ok = rel_err(got, want)
+        # no noise floor exists for these inputs: typical pair tight, worst (cusp) pair loose, as above
+        assert np.median(err[ok]) <= 1e-9 and err.max() <= 5e-3, (np.median(err[ok]), err.max())
