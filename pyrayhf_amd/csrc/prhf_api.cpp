@@ -39,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
+int kLeanMinPoints = 129;                  // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
 constexpr double kWellConditioned = 1e-4;  // hybrid O mode reproduces the reference to 1e-10
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
@@ -197,7 +198,14 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq, wg_slots);
         // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
-        want_pairs = want_pairs || ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points > 128 && u.prof_end > u.prof_begin);
+        // the main loop needs the pair table: one more (small) kernel unless the caller's grid is cached - not
+        // worth it for a handful of pairs on a short grid, where the launch itself is the cost
+        const long long seg_pairs = (u.prof_end - u.prof_begin) * n_freq;
+        // (decided from the slice's shape alone: host and device callers must get the same arithmetic)
+        const bool table_is_cheap = seg_pairs >= 4096 || u.n_points >= 2048;
+        s.lean = ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
+                  table_is_cheap) ? 1 : 0;
+        want_pairs = want_pairs || s.lean != 0;
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
     // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup
@@ -373,6 +381,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         if (v >= 64) kTargetWaves = v;
     }
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
+    if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(129, std::atoi(lm));
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;

@@ -45,6 +45,8 @@ struct SegDev {
     // Faithful tier only: where 1 - X exceeds this at all 64 points of a wave-iteration the reduced
     // algebra is used instead of the reference's operation order (+inf: never).
     double well_conditioned;
+    int lean;                        // this slice uses the main loop (and KArgs::pairs); decided per slice so that a
+                                     // slice gets the same arithmetic alone and inside a mixed launch
 };
 
 struct KArgs {

@@ -833,7 +833,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
     const int C = uniform(sg.chunks);
     const int T = F * C;                           // < 2^31: n_freq <= 2^20, chunks <= n_points / 256
     const double* mult = a.mult + sg.mult_off;
-    const double2* pairs = a.pairs ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
+    const double2* pairs = (a.pairs && sg.lean) ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
     const int first_item = block_in_prof * W, round_items = blocks_per_prof * W;
     // Items are handed out first come, first served.  The SIMD arbiter favours its older waves: with a
