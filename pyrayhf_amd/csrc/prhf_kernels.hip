@@ -915,14 +915,20 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 
 }  // namespace
 
+// Returns the wall clock at the end of staging in -DPRHF_TRACE builds (0 otherwise).
 template <int TIER, int THREADS>
-__device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
+__device__ __forceinline__ unsigned long long run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
                                           unsigned short* hint, double* red, long long prof_local,
                                           int block_in_prof, int blocks_per_prof, int* item_next) {
     const long long p = sg.prof_begin + prof_local;
     const BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
+#ifdef PRHF_TRACE
+    const unsigned long long t_staged = wall_clock64();
+#else
+    const unsigned long long t_staged = 0;
+#endif
     if (threadIdx.x == 0 && block_in_prof == 0) {
         if (info.bad) atomicOr(a.status, (unsigned)info.bad);
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
@@ -933,6 +939,7 @@ __device__ __forceinline__ void run_block(const KArgs& a, const SegDev& sg, Node
     else
         run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
+    return t_staged;
 }
 
 // TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
@@ -975,15 +982,16 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         const long long prof_local = prof0 + lb / bpp;
         const int block_in_prof = (int)(lb % bpp);
 
-        if (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-            run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
-        else
-            run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
+        const unsigned long long t_staged = (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
+            ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next)
+            : run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
+        (void)t_staged;
 #ifdef PRHF_TRACE
         if (a.trace && (threadIdx.x & 63) == 0) {
-            unsigned long long* t = a.trace + (bid * (THREADS / 64) + (threadIdx.x >> 6)) * 2;
+            unsigned long long* t = a.trace + (bid * (THREADS / 64) + (threadIdx.x >> 6)) * 3;
             t[0] = t_start;
             t[1] = wall_clock64();
+            t[2] = t_staged;
         }
 #endif
         if (a.queue == nullptr) break;

@@ -11,7 +11,7 @@ alt, den, bmag, bpsi = synth.chapman_profiles(12500, 20260004)
 t = [torch.as_tensor(x, device=dev) for x in (synth.sounder_frequencies(4), den, bmag, bpsi, alt)]
 for _ in range(2):
     library.vertical_forward_operator(*t, "X", 20000)
-w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 2).astype(np.float64) / 100.0     # us (100 MHz wall clock)
+w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 3).astype(np.float64) / 100.0  # us (100 MHz wall clock): start, end, staged
 t0 = w[:, :, 0].min()
 start, end = w[:, :, 0] - t0, w[:, :, 1] - t0
 wg_start, wg_end = start.min(axis=1), end.max(axis=1)
@@ -24,6 +24,8 @@ print(json.dumps({"workgroups": int(w.shape[0]), "kernel_us": float(wg_end.max()
                   "median_wave_done_frac_of_life": float(((np.median(end, axis=1) - wg_start) / life).mean())}))
 print("mean finish time of wave w as a fraction of its workgroup's life:",
       [round(float(x), 3) for x in ((end - wg_start[:, None]) / life[:, None]).mean(axis=0)])
+print("staging time per workgroup [us]: mean %.2f  p90 %.2f" % ((w[:, :, 2] - w[:, :, 0]).max(axis=1).mean(),
+                                                                  np.percentile((w[:, :, 2] - w[:, :, 0]).max(axis=1), 90)))
 print("mean start delay of wave w [us]:", [round(float(x), 2) for x in (start - wg_start[:, None]).mean(axis=0)])
 # resident workgroups over time
 edges = np.linspace(0, wg_end.max(), 41)
