@@ -862,14 +862,12 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
             // running maximum never reaches 1 (:399) and the level scan can be skipped - it is most of the
             // per-pair cost when n_points is small.  (K == 1 keeps the full path: np.interp's one-node quirk.)
             int scan = 1;
-#ifndef PRHF_NO_ESCAPE_TEST
             if (info.K > 1) {
 #pragma clang fp contract(off)
                 double ub = keep[kKeepPf2Max] / f2;
                 if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] / f_hz;
                 scan = uniform((int)!(ub < 1.0));
             }
-#endif
             if (scan) {
                 reflects = uniform((int)reflection_height<MODE>(nodes, pf2, gb, info.K, f_hz, f2, lane, &h)) != 0;
                 h = uniform(h);
