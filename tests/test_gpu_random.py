@@ -105,3 +105,31 @@ def test_non_uniform_grid_at_full_resolution():
         err, ok = rel_err(got, want)
         # no noise floor exists for these inputs: typical pair tight, worst (cusp) pair loose, as above
         assert np.median(err[ok]) <= 1e-9 and err.max() <= 5e-3, (np.median(err[ok]), err.max())
+
+
+@pytest.mark.parametrize("n_alt", [700, 1400])
+def test_tall_profiles_one_workgroup_per_cu(n_alt):
+    """More than 674 levels: a profile's nodes no longer fit twice into a CU's LDS (one workgroup per CU);
+    1400 is the limit of the interface, 1401 is refused."""
+    from oracle import vfo_c
+    from pyrayhf_amd import library
+    if not vfo_c.available():
+        pytest.skip("oracle/libvfo_oracle.so not built")
+    rng = np.random.default_rng(n_alt)
+    alt = np.linspace(80.0, 700.0, n_alt)
+    hm = rng.uniform(250.0, 400.0, (6, 1)); h = rng.uniform(35.0, 70.0, (6, 1))
+    z = (alt[None, :] - hm) / h
+    den = 10.0 ** rng.uniform(11.5, 12.3, (6, 1)) * np.exp(0.5 * (1.0 - z - np.exp(-z)))
+    bmag = 4.5e-5 * ((6371.0 + 80.0) / (6371.0 + alt[None, :])) ** 3 * np.ones((6, 1))
+    bpsi = rng.uniform(5.0, 85.0, (6, 1)) + 0.001 * (alt[None, :] - 80.0)
+    freq = np.linspace(1.0, 12.0, 40)
+    for n_points in (129, 191, 192, 193, 320, 2048):
+        want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", n_points)
+        got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n_points)
+        assert_masks(got, want)
+        err, ok = rel_err(got, want)
+        assert ok.sum() > 50 and err.max() <= 1e-8, (n_points, err.max())
+    if n_alt == 1400:
+        alt2 = np.linspace(80.0, 700.0, 1401)
+        with pytest.raises(ValueError):
+            library.vertical_forward_operator(freq, np.ones((1, 1401)), np.ones((1, 1401)), np.ones((1, 1401)), alt2, "X", 200)
