@@ -144,13 +144,15 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     *mup_out = mu - ((2.0 * X) * dmudX + Y * dmudY);           // :254
 }
 
-// The same mu and mu' in reduced form.  With S2 = sin^2 psi, C2 = cos^2 psi, Y2 = Y^2:
-//   h = YT^2/2, alpha = h^2 + YL^2 (1-X)^2, beta = sqrt(alpha), D = (1-X) - h +- beta   (:217-229)
-//   mu^2 = N/D with N = D - X(1-X)                                                    (:232)
-//   1/(2 mu D) = sign(D) / (2 sqrt(N D))  -> one rsqrt gives mu, 1/D and that factor
-//   Y dD/dY = -2h +- (beta + h^2/beta)      (from :244-247, using Y d(alpha)/dY = 4h^2 + 2 YL^2 (1-X)^2)
-//   t = YL^2 (1-X), so alpha = h^2 + t (1-X) and dD/dX = -1 -+ t/beta                (:241-242)
-//   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X(1-X)/D        (:250-254)
+// The same mu and mu' in reduced form.  With S2 = sin^2 psi, Y2 = Y^2, a = 1 - X, s = +1 (O) / -1 (X):
+//   h = YT^2/2,  t = YL^2 a,  alpha = h^2 + t a,  beta = sqrt(alpha),  D = a - h + s beta          (:217-229)
+//   mu^2 = N/D with N = D - X a;  w = 1/sqrt(N D) gives mu = |N w| and 1/(2 mu D) = sign(D) w / 2   (:232)
+//   dD/dX = -1 - s t/beta,  Y dD/dY = -2h + s (beta + h^2/beta)                              (:241-247)
+//   mu' = mu - [2X (2X - 1 + q dD/dX) + q Y dD/dY] / (2 mu D),  q = X a / D = 1 - mu^2       (:250-254)
+// Collecting the bracket and eliminating beta + (h^2 - 2Xt)/beta through D itself
+// (s h^2/beta = D - a + h - s t a/beta) leaves
+//   mu' = sign(D) w [ D - X^2 + q (1 - D + s t (1 + X) / (2 beta)) ]
+// - 7 operations after w (checked against the long form to 6e-16 on 1e5 random points per mode).
 // YL^2 = Y2 - Y2 S2 (absolute error 1e-16 Y2: harmless, YL^2 only enters through alpha and t).
 // index_fast_core leaves the validity test (:233, :238) to the caller and hands out q = X(1-X)/D.
 // The reference keeps a point when 0 <= fl(1 - q) and sqrt(fl(1 - q)) <= 1.  In vacuum (X -> 0) mu
@@ -174,8 +176,7 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double t = YL2 * Xm1;
     const double alpha = h2 + t * Xm1;
     const double rbeta = rsqrt_tier<MODE>(alpha);
-    const double beta = alpha * rbeta;
-    const double D = (Xm1 - h) + sgn * beta;
+    const double D = (Xm1 - h) + sgn * (alpha * rbeta);
     const double XXm1 = X * Xm1;
     const double N = D - XXm1;
     const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
@@ -183,17 +184,13 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double mu = __builtin_fabs(Nw);
     // q = X(1-X)/D = 1 - mu^2.  The generic callers test q against the mu > 1 cliff at the 1e-16 level and
     // need its sign exact: q = X(1-X) * (N w^2).  The main loop (POSD) has no such test and takes
-    // 1 - (N w)^2: two instructions fewer, absolute error ~1e-15 (q only enters through q * inner, inner = O(Y)).
+    // 1 - (N w)^2: two instructions fewer, absolute error ~1e-15 (q only enters through q * J, J = O(Y)).
     const double q = POSD ? 1.0 - Nw * Nw : XXm1 * (Nw * w);
-    // half of the bracket 2X (2X - 1 + q dD/dX) + q Y dD/dY, with dD/dX = -1 -+ t/beta (:241-242) and
-    // Y dD/dY = -2h +- (beta + h^2/beta):  X (2X - 1) + q [+-(beta + (h^2 - 2X t)/beta)/2 - (X + h)],
-    // so that mu' = mu - bracket / (2 mu D) = mu - sign(D) w * half
-    const double two_X = X + X;
-    const double inner = (0.5 * sgn) * ((h2 - two_X * t) * rbeta + beta) - (X + h);
-    const double half = q * inner + (two_X * X - X);
+    const double J = (t * rbeta) * ((0.5 * sgn) * X + (0.5 * sgn)) + (1.0 - D);
+    const double U = q * J + (D - X * X);
     const double A = POSD ? w : __builtin_copysign(w, D);
     *mu_out = mu;
-    *mup_out = mu - A * half;
+    *mup_out = A * U;
     *q_out = q;
 }
 
