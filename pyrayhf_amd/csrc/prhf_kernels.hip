@@ -14,7 +14,7 @@
 //
 // Two arithmetic tiers (DESIGN.md "Arithmetic tiers"):
 //   TIER 0 "faithful": the reference's operation order, IEEE divide and sqrt, no contraction;
-//   TIER 1 "fast":     algebraically reduced mu' (45 FP64 operations + 2 v_rsq_f64 per point on
+//   TIER 1 "fast":     algebraically reduced mu' (38 FP64 operations + 2 v_rsq_f64 per point on
 //                      the main loop), sin^2(psi) by a per-segment cubic, FMA contraction.
 //
 // No MFMA: the work is elementwise float64 transcendental + reduction ("Roofline").
