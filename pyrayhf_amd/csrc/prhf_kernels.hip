@@ -599,25 +599,13 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
     double2 ua = make_double2(r_ua.x, r_ua.y);                     // u0, u1
     double2 ub = make_double2(r_ub.x, r_ub.y);                     // u2, u3
-    // keep the whole node read ahead of the (almost never taken) branch: one LDS round trip
-    asm volatile("" :: "v"(dd.x), "v"(dd.y), "v"(bb.x), "v"(bb.y), "v"(ua.x), "v"(ua.y), "v"(ub.x));
-    if (!QUAD) asm volatile("" :: "v"(ub.y));
     double x = __builtin_fma(m0, span, off);                   // z - alt_j with z = m*span + a0 (:413)
-    // The closed-form index can miss by one where z rounds onto a level.  One segment too low is
-    // harmless (a linear piece evaluated 1e-13 km past its end); one too high would extrapolate to
-    // the LEFT of level j, where a zero density turns negative: that side restores np.interp's
-    // exact segment alt[j] <= z < alt[j+1].
-    if (HINT) {
-        x = fmax(x, 0.0);                                      // alt[j] <= z holds; this only absorbs rounding
-    } else if (__builtin_expect(__any(x < 0.0), 0)) {
-        const double z = __builtin_fma(m0, span, a0);
-        while (j > 0 && z < nodes[j].alt) --j;
-        while (j + 1 < K && z >= nodes[j + 1].alt) ++j;
-        const Node nd = nodes[j];
-        off = nd.off; dd = make_double2(nd.den, nd.sden); bb = make_double2(nd.b, nd.sb);
-        ua = make_double2(nd.u0, nd.u1); ub = make_double2(nd.u2, nd.u3);
-        x = fmax(__builtin_fma(m0, span, off), 0.0);
-    }
+    // The closed-form index can miss by one where z rounds onto a level (or, on a grid that is uniform
+    // only to 1e-9 per step, within 1e-6 km of one).  One segment too low is harmless: a linear piece
+    // evaluated that far past its right end.  One too high would extrapolate to the LEFT of level j, where a
+    // zero density turns negative: clamping x at 0 evaluates the level itself instead - the value the
+    // segment below has at its right end.
+    x = fmax(x, 0.0);
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
     const double S2 = QUAD ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y));
