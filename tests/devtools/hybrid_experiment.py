@@ -63,16 +63,17 @@ def report(tag, res, want, noise):
               f"within 1e-6: {np.mean(err[ok] <= 1e-6):.4f}")
 
 
-thr = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-4
-g4 = np.load(os.path.join(ROOT, "tests", "golden", "g4_day_night.npz"))
-for who in ("Day", "Night"):
-    for n in (200, 2000, 20000):
-        res = evaluate(g4["freq"], *(g4[f"{who}_{k}"] for k in ("den", "bmag", "bpsi", "alt")), "O", n, thr)
-        report(f"G4 {who} O/{n} (faithful share {res['share_faithful']:.3f})", res, g4[f"{who}_O_{n}_vh"], g4[f"{who}_O_{n}_noise"])
-g5 = np.load(os.path.join(ROOT, "tests", "golden", "g5_chapman64.npz"))
-rows = {k: [] for k in ("faithful", "fast", "hybrid")}
-for p in range(g5["den"].shape[0]):
-    res = evaluate(g5["freq"], g5["den"][p], g5["bmag"][p], g5["bpsi"][p], g5["alt"], "O", 200, thr)
-    for k in rows:
-        rows[k].append(res[k])
-report("G5 64 Chapman O/200", {k: np.array(v) for k, v in rows.items()}, g5["O_200_vh"], g5["O_200_noise"])
+if __name__ == "__main__":
+    thr = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-4
+    g4 = np.load(os.path.join(ROOT, "tests", "golden", "g4_day_night.npz"))
+    for who in ("Day", "Night"):
+        for n in (200, 2000, 20000):
+            res = evaluate(g4["freq"], *(g4[f"{who}_{k}"] for k in ("den", "bmag", "bpsi", "alt")), "O", n, thr)
+            report(f"G4 {who} O/{n} (faithful share {res['share_faithful']:.3f})", res, g4[f"{who}_O_{n}_vh"], g4[f"{who}_O_{n}_noise"])
+    g5 = np.load(os.path.join(ROOT, "tests", "golden", "g5_chapman64.npz"))
+    rows = {k: [] for k in ("faithful", "fast", "hybrid")}
+    for p in range(g5["den"].shape[0]):
+        res = evaluate(g5["freq"], g5["den"][p], g5["bmag"][p], g5["bpsi"][p], g5["alt"], "O", 200, thr)
+        for k in rows:
+            rows[k].append(res[k])
+    report("G5 64 Chapman O/200", {k: np.array(v) for k, v in rows.items()}, g5["O_200_vh"], g5["O_200_noise"])

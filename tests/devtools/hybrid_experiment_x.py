@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import vfo_numpy as orc
 from parity import rel_err
-from hybrid_experiment import mup_fast          # noqa: E402  (runs its report on import; harmless)
+from hybrid_experiment import mup_fast          # noqa: E402
 
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-3
 g4 = np.load(os.path.join(ROOT, "tests", "golden", "g4_day_night.npz"))
