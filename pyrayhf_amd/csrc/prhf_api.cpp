@@ -736,6 +736,12 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         a.prof_idx = profile_index ? d_i : nullptr;
         a.out = d_out; a.path_x = d_px; a.path_z = d_pz;
     }
+    {
+        int rc2 = ensure(c, c->partial, (size_t)n_prof * 16);      // per-profile scalars (the operator's chunk scratch is free here)
+        if (rc2 != PRHF_OK) return rc2;
+        a.prof_info = static_cast<double*>(c->partial.p);
+        a.n_prof = n_prof;
+    }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(prhf::launch_snell(a, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

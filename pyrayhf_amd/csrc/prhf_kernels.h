@@ -124,6 +124,8 @@ struct SnellArgs {
     const double* freq_hz;       // (n_rays)
     const double* elev_deg;      // (n_rays)
     const long long* prof_idx;   // (n_rays) or null: every ray uses profile 0
+    double* prof_info;           // (n_prof, 2) scratch: max|B| and "has a negative density", filled by launch_snell
+    long long n_prof;
     double* out;                 // (n_rays, PRHF_SNELL_OUTPUTS)
     double* path_x;              // (n_rays, path_stride) or null
     double* path_z;
