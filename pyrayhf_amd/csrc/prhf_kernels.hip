@@ -380,7 +380,10 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             nd.sb = (bmag[k + 1] - b) / da;
             spsi = dp / da;
             turn = fabs(dp) * kDegToRad;
-            ragged |= (fabs(da - step0) > 1e-9 * fabs(step0)) ? 1 : 0;
+            // "uniform" must hold to 1e-11 per step: the main loop's closed-form segment index then misses a
+            // level by at most 1e-8 of a step, and evaluating a linear piece that far outside its segment is
+            // harmless (see lean_step); looser grids go through the hint table
+            ragged |= (fabs(da - step0) > 1e-11 * fabs(step0)) ? 1 : 0;
         } else {
             nd.sden = 0.0; nd.sb = 0.0;
         }
@@ -600,12 +603,13 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     double2 ua = make_double2(r_ua.x, r_ua.y);                     // u0, u1
     double2 ub = make_double2(r_ub.x, r_ub.y);                     // u2, u3
     double x = __builtin_fma(m0, span, off);                   // z - alt_j with z = m*span + a0 (:413)
-    // The closed-form index can miss by one where z rounds onto a level (or, on a grid that is uniform
-    // only to 1e-9 per step, within 1e-6 km of one).  One segment too low is harmless: a linear piece
-    // evaluated that far past its right end.  One too high would extrapolate to the LEFT of level j, where a
-    // zero density turns negative: clamping x at 0 evaluates the level itself instead - the value the
-    // segment below has at its right end.
-    x = fmax(x, 0.0);
+    // The closed-form index can miss by one where z rounds onto a level (or, on a grid that is uniform only
+    // to 1e-11 per step, within 1e-8 of a step of one): a linear piece is then evaluated that far outside
+    // its segment.  Past the right end that is exact to rounding.  Past the LEFT end of a segment that
+    // starts at a zero density it gives a density of -1e-8 x slope, i.e. X ~ -1e-9 at one point; this path
+    // has no mu > 1 cliff test such a value could trip (the generic path, which has one, clamps), and the
+    // effect on mu' there is of the same size - far below the reference's own noise.
+    if (HINT) x = fmax(x, 0.0);                                 // the table walk guarantees alt[j] <= z: rounding only
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
     const double S2 = QUAD ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y));
