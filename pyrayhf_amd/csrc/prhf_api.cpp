@@ -197,7 +197,6 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.well_conditioned = (c->math == PRHF_MATH_AUTO && s.tier == 0) ? kWellConditioned : HUGE_VAL;
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
         plan_slice(s, n_freq, wg_slots);
-        // the fast tier's main loop (whole wave-iterations, two at a time) reads the pair table
         // the main loop needs the pair table: one more (small) kernel unless the caller's grid is cached - not
         // worth it for a handful of pairs on a short grid, where the launch itself is the cost
         const long long seg_pairs = (u.prof_end - u.prof_begin) * n_freq;
