@@ -39,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
+constexpr size_t kPackBytes = 1u << 20;
 int kLeanMinPoints = 129;                  // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
 constexpr double kWellConditioned = 1e-4;  // hybrid O mode reproduces the reference to 1e-10
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
@@ -70,6 +71,7 @@ struct prhf_ctx {
     int64_t pairs_len = 0;
     unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1] block queue of persistent launches
     unsigned* h_status = nullptr;   // pinned
+    double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece
     unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
     unsigned long long* h_words = nullptr;   // pinned
     bool status_pending = false;
@@ -259,22 +261,42 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         double* d_alt = d_bpsi + (size_t)n_prof * n_alt;
         double* d_mult = d_alt + n_alt_rows * n_alt;
         d_out = d_mult + mult_len;
-        HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
-        if (n_prof > 0) {
-            HIP_TRY(hipMemcpy2DAsync(d_den, row_bytes, den, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
-                                     hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpy2DAsync(d_bmag, row_bytes, bmag, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
-                                     hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpy2DAsync(d_bpsi, row_bytes, bpsi, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
-                                     hipMemcpyHostToDevice, c->stream));
-        }
-        if (alt_stride) {
-            if (n_prof > 0)
-                HIP_TRY(hipMemcpy2DAsync(d_alt, row_bytes, alt, (size_t)alt_stride * 8, row_bytes, (size_t)n_prof,
-                                         hipMemcpyHostToDevice, c->stream));
+        const size_t in_elems = (size_t)(d_out - base);
+        if (in_elems * 8 <= kPackBytes && c->h_pack) {
+            // A small call (the reference's usual one: a single profile): six separate uploads from pageable
+            // memory cost more than the kernel.  Pack the inputs in the arena's own order into a pinned
+            // buffer and send them in one piece.  The buffer is reused by the next call, so the copy must
+            // have left it first: the previous call has synchronised unless it was asynchronous, which host
+            // buffers never are.
+            double* h = c->h_pack;
+            std::memcpy(h + (d_freq - base), freq, (size_t)n_freq * 8);
+            for (int64_t p = 0; p < n_prof; ++p) {
+                std::memcpy(h + (d_den - base) + (size_t)p * n_alt, den + (size_t)p * prof_stride, row_bytes);
+                std::memcpy(h + (d_bmag - base) + (size_t)p * n_alt, bmag + (size_t)p * prof_stride, row_bytes);
+                std::memcpy(h + (d_bpsi - base) + (size_t)p * n_alt, bpsi + (size_t)p * prof_stride, row_bytes);
+                if (alt_stride) std::memcpy(h + (d_alt - base) + (size_t)p * n_alt, alt + (size_t)p * alt_stride, row_bytes);
+            }
+            if (!alt_stride) std::memcpy(h + (d_alt - base), alt, row_bytes);
+            std::memcpy(h + (d_mult - base), mult, (size_t)mult_len * 8);
+            HIP_TRY(hipMemcpyAsync(base, h, in_elems * 8, hipMemcpyHostToDevice, c->stream));
         } else {
-            HIP_TRY(hipMemcpyAsync(d_alt, alt, row_bytes, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
+            if (n_prof > 0) {
+                HIP_TRY(hipMemcpy2DAsync(d_den, row_bytes, den, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                         hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpy2DAsync(d_bmag, row_bytes, bmag, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                         hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpy2DAsync(d_bpsi, row_bytes, bpsi, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                                         hipMemcpyHostToDevice, c->stream));
+            }
+            if (alt_stride) {
+                if (n_prof > 0)
+                    HIP_TRY(hipMemcpy2DAsync(d_alt, row_bytes, alt, (size_t)alt_stride * 8, row_bytes, (size_t)n_prof,
+                                             hipMemcpyHostToDevice, c->stream));
+            } else {
+                HIP_TRY(hipMemcpyAsync(d_alt, alt, row_bytes, hipMemcpyHostToDevice, c->stream));
+            }
         }
         a.freq = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.mult = d_mult;
         a.out = d_out;
@@ -346,7 +368,14 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     c->timed = true;
     c->status_pending = true;
 
-    if (!dev && out_elems && out)
+    // small results come back through the pinned buffer too (its upper half; the inputs of a call this small
+    // fit the lower one) and are handed over after the synchronisation below
+    const bool out_via_pack = !dev && out && out_elems && c->h_pack && out_elems * 8 <= kPackBytes / 4 &&
+                              (size_t)(d_out - static_cast<double*>(c->arena.p)) * 8 <= kPackBytes / 2;
+    double* h_out = c->h_pack ? c->h_pack + kPackBytes / 16 : nullptr;       // doubles: byte offset kPackBytes / 2
+    if (out_via_pack)
+        HIP_TRY(hipMemcpyAsync(h_out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
+    else if (!dev && out_elems && out)
         HIP_TRY(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
     if (!dev && post) {
         if (post->residual)
@@ -355,7 +384,9 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             HIP_TRY(hipMemcpyAsync(post->cost, d_cost, (size_t)n_prof * 8, hipMemcpyDeviceToHost, c->stream));
     }
     if (flags & PRHF_FLAG_ASYNC) return PRHF_OK;
-    return prhf_sync(c);
+    rc = prhf_sync(c);
+    if (out_via_pack) std::memcpy(out, h_out, out_elems * 8);
+    return rc;
 }
 
 }  // namespace
@@ -398,6 +429,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
             hipSuccess ||
         (e = hipMemset(c->d_status, 0, 2 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_words), 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 2 * sizeof(unsigned long long),
                            hipHostMallocDefault)) != hipSuccess ||
@@ -422,6 +454,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->pairs.p) (void)hipFree(c->pairs.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
     if (c->d_words) (void)hipFree(c->d_words);
     if (c->h_words) (void)hipHostFree(c->h_words);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
