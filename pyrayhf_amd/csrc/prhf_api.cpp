@@ -41,7 +41,7 @@ int fail(int code, const char* fmt, ...) {
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
 constexpr size_t kPackBytes = 1u << 20;
 int kLeanMinPoints = 129;                  // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
-constexpr double kWellConditioned = 1e-4;  // hybrid O mode reproduces the reference to 1e-10
+double kWellConditioned = 1e-4;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
@@ -411,6 +411,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         if (v >= 64) kTargetWaves = v;
     }
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
+    if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
     if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(129, std::atoi(lm));
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));

@@ -228,22 +228,45 @@ __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes
     double lmax = -__builtin_inf();
     int kstar = K;
     double col_star = 0.0;
-    for (int base = 0; base < K; base += 64) {
-        const int k = base + lane;
-        double col = -__builtin_inf();
-        if (k < K) {
-            col = pf2[k] / f2;                                          // :136 on (F,K)
-            if (MODE == PRHF_KMODE_X) col = col + gb[k] / f_hz;         // :157, :389
+    if (MODE == PRHF_KMODE_O) {
+        // O mode compares one rounded quotient with 1, which needs no division: fl(a / b) > 1 <=> a / b >
+        // 1 + 2^-53 (round to nearest even) <=> a - b > b 2^-53, where a - b is exact for b <= a <= 2b
+        // (Sterbenz) and beyond 2b the test is true either way.  The running maximum of the quotients is the
+        // quotient of the running maximum (division is monotone): two divisions per pair instead of one per
+        // level, the same values bit for bit.
+        const double ulp_half = f2 * 0x1p-53;
+        double amax = -__builtin_inf(), a_star = 0.0;
+        for (int base = 0; base < K; base += 64) {
+            const int k = base + lane;
+            const double a = (k < K) ? pf2[k] : -__builtin_inf();
+            const unsigned long long hit = __ballot((a - f2) > ulp_half);
+            if (hit) {
+                const int first = __ffsll((long long)hit) - 1;
+                kstar = base + first;
+                a_star = __shfl(a, first);
+                if (lane < first) amax = fmax(amax, a);
+                break;
+            }
+            amax = fmax(amax, a);
         }
-        const unsigned long long hit = __ballot(col > 1.0);
-        if (hit) {
-            const int first = __ffsll((long long)hit) - 1;
-            kstar = base + first;
-            col_star = __shfl(col, first);
-            if (lane < first) lmax = fmax(lmax, col);
-            break;
+        amax = wave_max(amax);
+        lmax = amax / f2;                       // :136; -inf stays -inf (no level below the first hit)
+        col_star = a_star / f2;
+    } else {
+        for (int base = 0; base < K; base += 64) {
+            const int k = base + lane;
+            double col = -__builtin_inf();
+            if (k < K) col = pf2[k] / f2 + gb[k] / f_hz;            // :136, :157, :389
+            const unsigned long long hit = __ballot(col > 1.0);
+            if (hit) {
+                const int first = __ffsll((long long)hit) - 1;
+                kstar = base + first;
+                col_star = __shfl(col, first);
+                if (lane < first) lmax = fmax(lmax, col);
+                break;
+            }
+            lmax = fmax(lmax, col);
         }
-        lmax = fmax(lmax, col);
     }
     const double below = wave_max(lmax);        // running maximum at level kstar-1
     double h;
