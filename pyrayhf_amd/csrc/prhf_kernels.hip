@@ -786,19 +786,24 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             first = uniform(r.first);
         }
     }
-    int i = first + lane;
+    // Generic loop over [first, i1).  Its wave-iterations are aligned to the END of the range - a short first
+    // one (low lanes idle), full ones after it - so that the points next to the reflection height, the
+    // expensive ones (reference order), share one full iteration instead of spilling into a nearly empty one.
+    const int n_iter = uniform((i1 - first + 63) >> 6);
+    int i = i1 - (n_iter << 6) + lane;             // below `first` only in the first iteration: idle lane
+    auto grid = [&](int idx) { return mult[idx < first ? first : (idx < last ? idx : last)]; };
     double m0 = 0.0, m1 = 0.0;
-    if (i < i1) {
-        m0 = mult[i];
-        m1 = mult[i < last ? i + 1 : last];
+    if (n_iter > 0) {
+        m0 = grid(i);
+        m1 = grid(i + 1);
     }
-    while (i < i1) {
+    for (int it = 0; it < n_iter; ++it) {
         // prefetch the next iteration's grid values; clamped, never conditional, so that the
         // compiler can count outstanding loads (s_waitcnt vmcnt(2)) instead of draining them
         const int inext = i + 64;
-        const int ic = inext < last ? inext : last;
-        const double n0 = mult[ic];
-        const double n1 = mult[ic < last ? ic + 1 : last];
+        const double n0 = grid(inext);
+        const double n1 = grid(inext + 1);
+        const bool active = i >= first;            // an idle lane carries the range's first point along
         double z, dh;
         if (TIER == 0) {
 #pragma clang fp contract(off)
@@ -826,7 +831,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         }
         const double mup = point_mup<MODE, TIER, UNMAG>(nd, dz, f_hz, f2, cX, cY2, poly_angle, well_conditioned);
         const double term = mup * dh;              // :288
-        if (term == term) acc = acc + term;        // nansum
+        if (active && term == term) acc = acc + term;              // nansum
         i = inext;
         m0 = n0;
         m1 = n1;
