@@ -118,3 +118,22 @@ def test_missing_library_is_a_loud_error(tmp_path, monkeypatch):
     env = dict(os.environ, PRHF_LIB=str(tmp_path / "nowhere" / "libprhf.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert "LOUD True" in out.stdout, out.stdout + out.stderr
+
+
+def test_header_constants_match_the_binding():
+    """#define values of include/prhf.h (codes, flags, modes, arithmetic settings) against pyrayhf_amd/_native.py."""
+    import re
+    from pyrayhf_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "prhf.h")).read()
+    defines = {m.group(1): int(m.group(2).rstrip("u"), 0)
+               for m in re.finditer(r"#define\s+(PRHF_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+)u?)\b", text)}
+    expect = {"PRHF_OK": _native.OK, "PRHF_EINVAL": _native.EINVAL, "PRHF_ENEGDEN": _native.ENEGDEN,
+              "PRHF_EPEAK0": _native.EPEAK0, "PRHF_EHIP": _native.EHIP, "PRHF_ENOMEM": _native.ENOMEM,
+              "PRHF_FLAG_DEVICE_PTRS": _native.FLAG_DEVICE_PTRS, "PRHF_FLAG_ASYNC": _native.FLAG_ASYNC,
+              "PRHF_FLAG_GRID_STABLE": _native.FLAG_GRID_STABLE, "PRHF_MODE_O": _native.MODE_O,
+              "PRHF_MODE_X": _native.MODE_X, "PRHF_MATH_FAITHFUL": _native.MATH_FAITHFUL,
+              "PRHF_MATH_FAST": _native.MATH_FAST, "PRHF_MATH_AUTO": _native.MATH_AUTO,
+              "PRHF_ABI_VERSION": _native.ABI_VERSION}
+    for name, value in expect.items():
+        assert defines.get(name) == value, (name, defines.get(name), value)
