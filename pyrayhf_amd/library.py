@@ -29,7 +29,7 @@ __all__ = [
 
 MATH_FAITHFUL = _native.MATH_FAITHFUL   # reference operation order, IEEE divide / sqrt
 MATH_FAST = _native.MATH_FAST           # reduced algebra, rsqrt + Newton, FMA contraction
-MATH_AUTO = _native.MATH_AUTO           # per slice: faithful for 'O', fast for 'X' (default)
+MATH_AUTO = _native.MATH_AUTO           # default, per slice: 'X' fast; 'O' reference order where 1 - X <= 1e-4, fast elsewhere
 
 
 # ----------------------------------------------------------------------------------------
@@ -291,8 +291,10 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     frequency is not reflected below the density peak.
 
     Keyword-only extensions: ``device`` (GPU index for host inputs; default ``PRHF_DEVICE``
-    / ``LOCAL_RANK`` / 0), ``math`` (``MATH_FAITHFUL`` / ``MATH_FAST``; default faithful for
-    'O', fast for 'X'),
+    / ``LOCAL_RANK`` / 0), ``math`` (``MATH_FAITHFUL``: the reference's operation order at every
+    grid point; ``MATH_FAST``: the reduced algebra at every point; default ``MATH_AUTO``: fast for
+    'X'; for 'O' the reference's order where 1 - X <= 1e-4 - where it decides the answer - and the
+    reduced algebra elsewhere, which reproduces the reference to 1e-10),
     and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
 
     Raises ``ValueError("mode must be 'O' or 'X'")``, ``ValueError("Density must be
