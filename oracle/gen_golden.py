@@ -18,6 +18,10 @@ Fixtures:
   G5  seeded synthetic batch (P=64) x 174 x {O/200, X/2000} + noise floors
   G6  stage captures (3 freqs of G4-Day, n_points=50)
   G7  edge cases
+  G8/G9  stratified Snell's-law rays, flat and spherical Earth
+  G10 the first 64 profiles of BASELINE config 3 (seed 20260003) x 174 freqs, O/200 + noise floors
+  G11 residual_VH (library.py:595-669) rows: the reference function itself, with model_VH replaced by
+      a stand-in that builds the EDP without PyIRI and calls the reference's own operator
 
 "noise" = max over NOISE_RUNS reference evaluations, each with every input perturbed by
 +-1 ulp at random, of |vh' - vh| / |vh| : the reference's own conditioning, used by the
@@ -246,6 +250,8 @@ def main():
     except Exception as exc:                   # noqa: BLE001
         print("negative density ->", type(exc).__name__, exc)
     gen_snell(lib)
+    gen_config3(lib)
+    gen_residual(lib)
     print("fixtures written to", OUT)
 
 
@@ -317,9 +323,98 @@ def gen_snell(lib):
     np.savez(os.path.join(OUT, "g9_snell_spherical.npz"), **g9)
 
 
+def gen_config3(lib):
+    """G10: the first 64 profiles of BASELINE config 3 (10 000 Chapman profiles, seed 20260003) x 174 freqs,
+    O mode, n_points = 200 - the configuration the O-mode tolerance is about - with the reference's own
+    +-1 ulp response per pair."""
+    from pyrayhf_amd import synth
+    rows = 64
+    alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003, rows=slice(0, rows))
+    freq = synth.sounder_frequencies(3)
+    vh = np.empty((rows, freq.size))
+    nz = np.empty_like(vh)
+    for p in range(rows):
+        vh[p], nz[p] = noise_floor(lib, freq, den[p], bmag[p], bpsi[p], alt, "O", 200, seed=20260003 + 7919 * p)
+    np.savez(os.path.join(OUT, "g10_config3_rows.npz"), freq=freq, alt=alt, den=den, bmag=bmag, bpsi=bpsi,
+             seed=20260003, n_points=200, O_200_vh=vh, O_200_noise=nz)
+    fin = np.isfinite(vh)
+    print("G10 reflecting fraction", float(fin.mean()), "noise > 1e-6 at", int((nz[fin] > 1e-6).sum()), "of",
+          int(fin.sum()), "pairs; max", float(nz[fin & np.isfinite(nz)].max()), flush=True)
+
+
+class _Param:
+    """What residual_VH reads from an lmfit.Parameters entry (library.py:645-653): `.value`."""
+    def __init__(self, value):
+        self.value = value
+
+
+def gen_residual(lib):
+    """G11: residual_VH itself (library.py:595-669).  It needs PyIRI only through model_VH (library.py:650),
+    which the reference's own test replaces (test_core.py:345-353: patch("PyRayHF.library.model_VH")).  The
+    stand-in here turns the F2 parameters residual_VH has just written (Nm, hm, B_bot; library.py:645-649)
+    into an alpha-Chapman EDP plus a fixed E layer and calls the REFERENCE's vertical_forward_operator with it,
+    exactly as the last lines of model_VH do (library.py:589-591) - so the fixture pins EDP -> operator ->
+    NaN fill (library.py:664-665) -> residual (library.py:668)."""
+    seen = []
+
+    def model_vh_stand_in(F2, F1, E, f_in, alt, b_mag, b_psi, mode='O', n_points=200, bottom_type='B_bot'):
+        z = (alt - F2['hm'].ravel()[0]) / F2['B_bot'].ravel()[0]
+        ze = (alt - E['hm'].ravel()[0]) / E['B_bot'].ravel()[0]
+        edp = (F2['Nm'].ravel()[0] * np.exp(0.5 * (1.0 - z - np.exp(-z)))
+               + E['Nm'].ravel()[0] * np.exp(0.5 * (1.0 - ze - np.exp(-ze))))
+        seen.append(edp)
+        vh = lib.vertical_forward_operator(f_in, edp, b_mag, b_psi, alt, mode=mode, n_points=n_points)
+        return vh, edp
+
+    lib.model_VH = model_vh_stand_in
+    one = lambda v: np.array([[[v]]])                                            # noqa: E731
+    g11 = {}
+    cases = {
+        # candidates around a "true" layer: lower NmF2 -> the top frequencies escape (NaN -> filled)
+        "grid": dict(alt=np.arange(80.0, 500.0, 1.0), f_in=np.arange(1.0, 9.8, 0.25), E=(3e10, 110.0, 8.0),
+                     truth=(1.2e12, 300.0, 45.0),
+                     cand=[(nm, hm, bb) for nm in (0.4e12, 0.9e12, 1.2e12, 1.6e12) for hm in (270.0, 300.0, 335.0)
+                           for bb in (38.0, 45.0)]),
+        # every modeled height NaN (sounder above foF2 of every candidate): nanmean of nothing -> NaN row
+        "all_nan": dict(alt=np.arange(80.0, 500.0, 1.0), f_in=np.array([13.0, 14.0, 15.5]), E=(3e10, 110.0, 8.0),
+                        truth=(3.0e12, 300.0, 45.0), cand=[(1.0e12, 300.0, 45.0), (1.2e12, 280.0, 40.0)]),
+        # low layer: mean |vh| < 100 km -> NaNs filled with 100 (library.py:664-665)
+        "low_layer": dict(alt=np.arange(20.0, 160.0, 0.5), f_in=np.arange(1.0, 8.55, 0.5), E=(1e9, 30.0, 4.0),
+                          truth=(9e11, 70.0, 9.0), cand=[(4e11, 66.0, 8.0), (9e11, 70.0, 9.0), (6e11, 75.0, 10.0)]),
+    }
+    for name, c in cases.items():
+        alt, f_in = c["alt"], c["f_in"]
+        b_mag = 4.6e-5 * ((6371.0 + 80.0) / (6371.0 + alt)) ** 3
+        b_psi = 35.0 + 0.002 * (alt - alt[0])
+        E = {"Nm": one(c["E"][0]), "hm": one(c["E"][1]), "B_bot": one(c["E"][2])}
+        F1 = {"Nm": one(0.0), "hm": one(200.0), "B_bot": one(30.0)}
+        for mode, n_points in (("O", 200), ("X", 2000)):
+            F2 = {"Nm": one(c["truth"][0]), "hm": one(c["truth"][1]), "B_bot": one(c["truth"][2])}
+            vh_obs, _ = model_vh_stand_in(F2, F1, E, f_in, alt, b_mag, b_psi, mode, n_points)
+            del seen[:]
+            rows = []
+            for nm, hm, bb in c["cand"]:
+                params = {"NmF2": _Param(nm), "hmF2": _Param(hm), "B_bot": _Param(bb)}
+                rows.append(lib.residual_VH(params, F2, F1, E, f_in, vh_obs, alt, b_mag, b_psi, mode=mode,
+                                            n_points=n_points, bottom_type='B_bot'))
+            g11[f"{name}_{mode}_residual"] = np.array(rows)
+            g11[f"{name}_{mode}_vh_obs"] = vh_obs
+            g11[f"{name}_{mode}_n_points"] = n_points
+            g11[f"{name}_edp"] = np.array(seen)
+            print("G11", name, mode, "rows", len(rows), "NaN residuals", int(np.isnan(np.array(rows)).sum()),
+                  "escaping obs", int(np.isnan(vh_obs).sum()), flush=True)
+        for k, v in (("alt", alt), ("freq", f_in), ("bmag", b_mag), ("bpsi", b_psi)):
+            g11[f"{name}_{k}"] = v
+    g11["cases"] = np.array(sorted(cases))
+    np.savez(os.path.join(OUT, "g11_residual.npz"), **g11)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["g8"]:
+    only = sys.argv[1:]
+    if only:
         np.seterr(all="ignore")
-        gen_snell(load_reference_library())
+        ref = load_reference_library()
+        for what in only:
+            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual}[what](ref)
     else:
         main()

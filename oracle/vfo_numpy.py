@@ -207,8 +207,10 @@ def residual_rows(vh_obs, vh_model):
     """Residual rows of the fitting driver for a (P, F) batch of modeled traces.
 
     Restates reference library.py:660-669 (residual_VH) row by row: modeled NaNs are replaced by
-    max(nanmean(|vh_model|), 100), then residual = vh_obs - vh_model.  (The reference function
-    itself needs PyIRI and lmfit, which are not installed: parity for this row is unpinned.)
+    max(nanmean(|vh_model|), 100), then residual = vh_obs - vh_model.  Pinned: fixture G11 holds the
+    output of the reference's residual_VH itself (its PyIRI-dependent EDP builder replaced the way the
+    reference's own test replaces it) and tests/test_oracle_golden.py::test_residual_rows_g11 requires
+    this function to reproduce it bit for bit.
     """
     vh_model = np.array(vh_model, dtype=float, copy=True)
     with np.errstate(all="ignore"):

@@ -6,9 +6,10 @@
  *
  * One (profile, frequency) pair at a time, scalar loops, libm, float64, the reference's
  * operation order (reference PyRayHF/library.py:40-509; line numbers below are that file).
- * It differs from the reference's NumPy path only where libm differs from NumPy's SIMD
- * sin/cos/pow by an ulp and in the summation order (NumPy sums pairwise, this sums pairwise in
- * blocks of 128 too, see pairwise_nansum); tests/test_oracle_c.py holds it to the golden
+ * It differs from the reference's NumPy path only where NumPy's SIMD pow is not correctly
+ * rounded (~5 % of YT**4 / YT**3, by one ulp; sin/cos are the same libm calls) and, by an ulp of
+ * the sum, in the summation order (NumPy sums pairwise; so does pairwise_sum below, in the same
+ * blocks of 128).  NOT bit-identical to the reference: tests/test_oracle_c.py holds it to the golden
  * vectors of the reference at 1e-12 (X mode) and the noise-aware rule (O mode).
  *
  * Build: make -C oracle   (gcc -O2 -fopenmp -ffp-contract=off, no fast-math)
@@ -52,6 +53,20 @@ static double interp1(double x, const double* xp, const double* fp, const double
     return slope[j] * (x - xp[j]) + fp[j];
 }
 
+/* YT**4 and YT**3 (library.py:217, :244) are pow() calls in NumPy: one rounding.  Double-double products
+ * rounded once reproduce the correctly rounded value (checked against exact rationals, tests/test_oracle_c.py);
+ * glibc's pow does in 99.9 % of the cases, NumPy's SIMD pow in ~95 %, (x*x)*(x*x) in 50 %. */
+static double pow4_once(double x) {
+    const double h = x * x, l = fma(x, x, -h);
+    const double p = h * h, e = fma(h, h, -p);
+    return p + fma(2.0 * h, l, e);
+}
+static double pow3_once(double x) {
+    const double h = x * x, l = fma(x, x, -h);
+    const double p = h * x, e = fma(h, x, -p);
+    return p + fma(l, x, e);
+}
+
 /* library.py:161-256; mode: 0 = O, 1 = X.  Returns mu' (NaN where the reference has NaN). */
 static double group_index(double X, double Y, double psi_deg, int mode, int unmag) {
     if (unmag) {                                     /* :201-207 */
@@ -64,7 +79,7 @@ static double group_index(double X, double Y, double psi_deg, int mode, int unma
     const double s = sin(r), c = cos(r);
     const double YT = Y * s, YL = Y * c;             /* :210-211 */
     const double Xm1 = 1.0 - X;                      /* :214 */
-    const double alpha = 0.25 * pow(YT, 4.0) + (YL * YL) * (Xm1 * Xm1);   /* :217 */
+    const double alpha = 0.25 * pow4_once(YT) + (YL * YL) * (Xm1 * Xm1);   /* :217 */
     const double beta = sqrt(alpha);                 /* :218 */
     const double D = (Xm1 - 0.5 * (YT * YT)) + sgn * beta;                /* :229 */
     double rad = 1.0 - X * Xm1 / D;                  /* :232 */
@@ -73,7 +88,7 @@ static double group_index(double X, double Y, double psi_deg, int mode, int unma
     if (mu > 1.0) mu = NAN;                          /* :238 */
     const double dbdX = (-(YL * YL)) * Xm1 / beta;   /* :241 */
     const double dDdX = -1.0 + sgn * dbdX;           /* :242 */
-    const double dadY = pow(YT, 3.0) * s + ((2.0 * YL) * (Xm1 * Xm1)) * c;   /* :244-245 */
+    const double dadY = pow3_once(YT) * s + ((2.0 * YL) * (Xm1 * Xm1)) * c;   /* :244-245 */
     const double dbdY = 0.5 * dadY / beta;           /* :246 */
     const double dDdY = (-YT) * s + sgn * dbdY;      /* :247 */
     const double dmudY = (X * Xm1 * dDdY) / (2.0 * mu * (D * D));            /* :250 */

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "prhf_crmath.h"
 #include "prhf_kernels.h"
 
 namespace prhf {
@@ -116,14 +117,17 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;   // library.py:221-224
     const double r = psi_deg * kDegToRad;
     double s, c;
-    sincos(r, &s, &c);
+    // sin, cos, YT**4 and YT**3 rounded the way the reference's libm / NumPy pow round them (prhf_crmath.h):
+    // near reflection D cancels to 1e-9 of its terms and these roundings decide the last grid points
+    if (__builtin_fabs(r) < 1.0e6) prhf_cr::sincos(r, &s, &c);
+    else sincos(r, &s, &c);
     const double YT = Y * s;                                   // :210
     const double YL = Y * c;                                   // :211
     const double Xm1 = 1.0 - X;                                // :214
     const double YT2 = YT * YT;
     const double YL2 = YL * YL;
     const double Xm12 = Xm1 * Xm1;
-    const double alpha = 0.25 * (YT2 * YT2) + YL2 * Xm12;      // :217
+    const double alpha = 0.25 * prhf_cr::pow4(YT) + YL2 * Xm12;  // :217 (YT**4 is a pow in NumPy)
     const double beta = sqrt(alpha);                           // :218
     const double D = (Xm1 - 0.5 * YT2) + sgn * beta;           // :229
     const double XXm1 = X * Xm1;
@@ -134,7 +138,7 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     if (mu > 1.0) mu = qnan();                                 // :238
     const double dbdX = ((-YL2) * Xm1) / beta;                 // :241
     const double dDdX = -1.0 + sgn * dbdX;                     // :242
-    const double dadY = (YT2 * YT) * s + ((2.0 * YL) * Xm12) * c;   // :244-245
+    const double dadY = prhf_cr::pow3(YT) * s + ((2.0 * YL) * Xm12) * c;   // :244-245
     const double dbdY = (0.5 * dadY) / beta;                   // :246
     const double dDdY = (-YT) * s + sgn * dbdY;                // :247
     const double two_mu = 2.0 * mu;

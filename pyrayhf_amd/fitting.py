@@ -9,9 +9,10 @@ residual rows and their sums of squares; everything stays in HBM in between.
 
 The profile builder stays with the caller: PyIRI is a third-party dependency that is not vendored
 by the reference (``pyproject.toml:43``), so this module takes the candidate densities as an array.
-Parity note: ``residual_VH`` itself cannot be run without PyIRI and lmfit; the NaN-fill and
-residual arithmetic below restate ``library.py:660-669`` and are checked against the oracle's
-restatement (parity unpinned against the live reference for this row).
+Parity: fixture G11 (``tests/golden/g11_residual.npz``) holds residual rows produced by the reference's
+``residual_VH`` itself - its PyIRI-dependent ``model_VH`` replaced, as the reference's own test does
+(``test_core.py:345-353``), by a stand-in that calls the reference's operator on an EDP stored in the
+fixture; ``tests/test_gpu_fitting.py`` holds this module to those rows.
 """
 
 from __future__ import annotations
@@ -36,13 +37,14 @@ def _sorted_finite(freq, vh_obs):
 
 
 def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200, *, device=None, math=None,
-                      return_cost=True):
+                      return_cost=True, return_vh=False):
     """Residual rows ``vh_obs - vh_model`` for a batch of candidate density profiles.
 
     ``den`` is ``(P, N_alt)`` (one row per candidate); ``bmag, bpsi`` are ``(N_alt,)`` (shared, as
     in the reference's fit) or ``(P, N_alt)``; ``alt`` ``(N_alt,)``.  ``freq`` (MHz) and ``vh_obs``
     (km) are used as given (no filtering or sorting).  Returns ``(residual (P, F), cost (P,))`` with
-    ``cost = sum(residual**2, axis=1)``, or only ``residual`` when ``return_cost`` is false.
+    ``cost = sum(residual**2, axis=1)``, or only ``residual`` when ``return_cost`` is false; with
+    ``return_vh`` the modeled traces ``(P, F)`` (NaN where a frequency escapes) are appended.
     """
     code = _mode_code(mode)
     f = np.ascontiguousarray(np.atleast_1d(freq), dtype=np.float64)
@@ -59,13 +61,18 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
     mult = _multiplier(n_points)
     residual = np.empty((n_prof, f.size), dtype=np.float64)
     cost = np.empty(n_prof, dtype=np.float64)
+    vh = np.empty((n_prof, f.size), dtype=np.float64) if return_vh else None
     ctx = _native.context(device)
     ctx.set_math(MATH_AUTO if math is None else int(math))
     # one call: candidates staged once, modeled traces stay in HBM between the two kernels
     _native.raise_for(ctx.vfo_residual(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data,
                                        a.ctypes.data, n_prof, n_alt, n_alt, 0, mult.ctypes.data, int(n_points), code,
-                                       obs.ctypes.data, None, residual.ctypes.data, cost.ctypes.data, 0))
-    return (residual, cost) if return_cost else residual
+                                       obs.ctypes.data, vh.ctypes.data if return_vh else None,
+                                       residual.ctypes.data, cost.ctypes.data, 0))
+    out = (residual, cost) if return_cost else (residual,)
+    if return_vh:
+        out = out + (vh,)
+    return out if len(out) > 1 else out[0]
 
 
 def brute_force_fit(freq, vh_obs, den_candidates, bmag, bpsi, alt, mode='O', n_points=200, *, device=None,
@@ -76,16 +83,18 @@ def brute_force_fit(freq, vh_obs, den_candidates, bmag, bpsi, alt, mode='O', n_p
     reference's ``minimize_parameters`` (library.py:794-798), whose objective for an array residual is
     its sum of squares.  Observations are filtered to finite values and sorted by frequency first
     (library.py:741-745).  Returns ``(best_index, cost (P,), vh_best (F_used,), freq_used)``;
-    ties go to the first node, as in a grid scan.
+    ``vh_best`` is the modeled trace of the best node as the operator returns it (NaN where a
+    frequency escapes, like the final ``model_VH`` call of the reference, library.py:821-824), not the
+    NaN-filled one the residual was computed from.  Ties go to the first node, as in a grid scan.
     """
     f, obs = _sorted_finite(freq, vh_obs)
-    residual, cost = residual_VH_batch(f, obs, den_candidates, bmag, bpsi, alt, mode, n_points, device=device,
-                                       math=math)
+    residual, cost, vh = residual_VH_batch(f, obs, den_candidates, bmag, bpsi, alt, mode, n_points, device=device,
+                                           math=math, return_vh=True)
     finite = np.isfinite(cost)
     if not finite.any():
         raise ValueError("no candidate profile produced a finite cost")
     best = int(np.argmin(np.where(finite, cost, np.inf)))
-    return best, cost, obs - residual[best], f
+    return best, cost, vh[best], f
 
 
 def peak_density_from_trace(f_max_mhz, mode='O', *, alt=None, bmag=None, hmf2=None):
