@@ -22,6 +22,9 @@ Fixtures:
   G10 the first 64 profiles of BASELINE config 3 (seed 20260003) x 174 freqs, O/200 + noise floors
   G11 residual_VH (library.py:595-669) rows: the reference function itself, with model_VH replaced by
       a stand-in that builds the EDP without PyIRI and calls the reference's own operator
+  G12 (made with the ORACLE, not the reference: it needs a hook inside find_mu_mup) "rounding noise" of
+      every O-mode fixture above: the response of the restated algorithm - bit-identical to the
+      reference on G1-G11 - to -1/0/+1 ulp in the results of sin, cos, YT**4, YT**3
 
 "noise" = max over NOISE_RUNS reference evaluations, each with every input perturbed by
 +-1 ulp at random, of |vh' - vh| / |vh| : the reference's own conditioning, used by the
@@ -252,6 +255,7 @@ def main():
     gen_snell(lib)
     gen_config3(lib)
     gen_residual(lib)
+    gen_rounding_noise(lib)
     print("fixtures written to", OUT)
 
 
@@ -409,12 +413,39 @@ def gen_residual(lib):
     np.savez(os.path.join(OUT, "g11_residual.npz"), **g11)
 
 
+def gen_rounding_noise(lib):
+    """G12.  The input-jitter noise floors of G4/G5/G10 miss one thing: NumPy's pow is not correctly rounded
+    (~5 % of YT**4 are one ulp off, systematically over whole argument ranges, so +-1 ulp on the INPUTS does
+    not flip it), and where D cancels (library.py:229) that one ulp moves a pair by up to 1e-5.  An
+    implementation with a different - even an exactly rounding - math library differs from the reference by
+    this much, so the parity rule prices it in: max(input noise, rounding noise)."""
+    del lib                                                # made with the pinned oracle
+    from oracle import vfo_numpy as orc
+    g12 = {}
+    g4 = dict(np.load(os.path.join(OUT, "g4_day_night.npz")))
+    for which in ("Day", "Night"):
+        for n in (200, 2000, 20000):
+            g12[f"g4_{which}_O_{n}"] = orc.rounding_noise(g4["freq"], g4[f"{which}_den"], g4[f"{which}_bmag"],
+                                                           g4[f"{which}_bpsi"], g4[f"{which}_alt"], "O", n,
+                                                           runs=NOISE_RUNS, seed=n)
+            print("G12", which, n, float(np.nanmax(g12[f"g4_{which}_O_{n}"])), flush=True)
+    for name, fname in (("g5", "g5_chapman64.npz"), ("g10", "g10_config3_rows.npz")):
+        g = dict(np.load(os.path.join(OUT, fname)))
+        g12[f"{name}_O_200"] = np.array([orc.rounding_noise(g["freq"], g["den"][p], g["bmag"][p], g["bpsi"][p],
+                                                             g["alt"], "O", 200, runs=NOISE_RUNS, seed=p)
+                                         for p in range(g["den"].shape[0])])
+        fin = np.isfinite(g["O_200_vh"])
+        print("G12", name, "rounding noise > 1e-6 at", int((g12[f"{name}_O_200"][fin] > 1e-6).sum()), "of",
+              int(fin.sum()), "; input noise > 1e-6 at", int((g["O_200_noise"][fin] > 1e-6).sum()), flush=True)
+    np.savez(os.path.join(OUT, "g12_rounding_noise.npz"), **g12)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
         np.seterr(all="ignore")
         ref = load_reference_library()
         for what in only:
-            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual}[what](ref)
+            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual, "g12": gen_rounding_noise}[what](ref)
     else:
         main()

@@ -110,10 +110,23 @@ def stretched_columns(f_hz, den, bmag, bpsi, alt, mode, n_points):
     }
 
 
-def phase_group_index(X, Y, psi_deg, mode):
+def _ulp_nudge(rng, a):
+    """a with every element moved by -1, 0 or +1 ulp at random (used only by the rounding-noise model)."""
+    step = rng.integers(-1, 2, size=np.shape(a))
+    up = np.nextafter(a, np.inf)
+    down = np.nextafter(a, -np.inf)
+    return np.where(step > 0, up, np.where(step < 0, down, a))
+
+
+def phase_group_index(X, Y, psi_deg, mode, rounding_rng=None):
     """Appleton-Hartree phase index mu and group index mu'.
 
     Reference library.py:161-256 (find_mu_mup).  psi in degrees.
+
+    ``rounding_rng`` (a numpy Generator; default None = the reference's arithmetic exactly) is for the
+    tolerance model only: the results of the four library calls whose last bit differs between math
+    libraries - sin, cos, YT**4, YT**3 - are moved by -1/0/+1 ulp at random, which shows how far the
+    reference's own answer depends on them (fixture G12, tests/parity.py).
     """
     X = np.asarray(X, dtype=float)
     Y = np.asarray(Y, dtype=float)
@@ -128,10 +141,15 @@ def phase_group_index(X, Y, psi_deg, mode):
 
     s = np.sin(np.deg2rad(psi_deg))
     c = np.cos(np.deg2rad(psi_deg))
+    if rounding_rng is not None:
+        s, c = _ulp_nudge(rounding_rng, s), _ulp_nudge(rounding_rng, c)
     YT = Y * s                                              # library.py:210
     YL = Y * c                                              # library.py:211
     Xm1 = 1.0 - X                                           # library.py:214
-    alpha = 0.25 * YT ** 4 + YL ** 2 * Xm1 ** 2             # library.py:217
+    YT4, YT3 = YT ** 4, YT ** 3
+    if rounding_rng is not None:
+        YT4, YT3 = _ulp_nudge(rounding_rng, YT4), _ulp_nudge(rounding_rng, YT3)
+    alpha = 0.25 * YT4 + YL ** 2 * Xm1 ** 2                 # library.py:217
     beta = np.sqrt(alpha)                                   # library.py:218
     if mode == "O":
         sign = 1.0
@@ -148,7 +166,7 @@ def phase_group_index(X, Y, psi_deg, mode):
 
     dbeta_dX = -YL ** 2 * Xm1 / beta                        # library.py:241
     dD_dX = -1.0 + sign * dbeta_dX                          # library.py:242
-    dalpha_dY = YT ** 3 * s + 2.0 * YL * Xm1 ** 2 * c       # library.py:244-245
+    dalpha_dY = YT3 * s + 2.0 * YL * Xm1 ** 2 * c           # library.py:244-245
     dbeta_dY = 0.5 * dalpha_dY / beta                       # library.py:246
     dD_dY = -YT * s + sign * dbeta_dY                       # library.py:247
     dmu_dY = (X * Xm1 * dD_dY) / (2.0 * mu * D ** 2)        # library.py:250
@@ -157,15 +175,15 @@ def phase_group_index(X, Y, psi_deg, mode):
     return mu, mup
 
 
-def group_path(X, Y, psi_deg, thickness, alt_min, mode):
+def group_path(X, Y, psi_deg, thickness, alt_min, mode, rounding_rng=None):
     """Left-rectangle sum of mu' * dh per frequency row; reference library.py:259-293."""
-    _, mup = phase_group_index(X, Y, psi_deg, mode)
+    _, mup = phase_group_index(X, Y, psi_deg, mode, rounding_rng)
     total = np.nansum(mup * thickness, axis=1)
     total[total == 0] = np.nan
     return total + alt_min
 
 
-def virtual_heights(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200):
+def virtual_heights(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200, rounding_rng=None):
     """One profile, all frequencies; reference library.py:459-509."""
     with np.errstate(all="ignore"):
         f_hz = np.atleast_1d(np.asarray(freq_mhz, dtype=float)) * 1e6
@@ -173,7 +191,53 @@ def virtual_heights(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200):
         cols = stretched_columns(f_hz, den, bmag, bpsi, alt, mode, n_points)
         X = ratio_X(cols["den"], cols["freq"])
         Y = ratio_Y(cols["freq"], cols["bmag"])
-        return group_path(X, Y, cols["bpsi"], cols["dist"], np.min(alt), mode)
+        return group_path(X, Y, cols["bpsi"], cols["dist"], np.min(alt), mode, rounding_rng)
+
+
+def rounding_noise(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200, runs=24, seed=0):
+    """max over ``runs`` of |vh' - vh| / |vh| where vh' is the same evaluation with sin, cos, YT**4, YT**3
+    moved by -1/0/+1 ulp at random: the reference algorithm's own response to the last bit of its math
+    library (inf where the NaN mask flips).  One profile."""
+    base = virtual_heights(freq_mhz, den, bmag, bpsi, alt, mode, n_points)
+    rng = np.random.default_rng(seed)
+    worst = np.zeros_like(base)
+    for _ in range(runs):
+        v = virtual_heights(freq_mhz, den, bmag, bpsi, alt, mode, n_points, rounding_rng=rng)
+        both = np.isfinite(v) & np.isfinite(base)
+        rel = np.where(both, np.abs(v - base) / np.abs(np.where(both, base, 1.0)), 0.0)
+        rel = np.where(np.isfinite(v) != np.isfinite(base), np.inf, rel)
+        worst = np.maximum(worst, rel)
+    return worst
+
+
+def _ulp_jitter(rng, a):
+    a = np.asarray(a, dtype=np.float64)
+    out = np.nextafter(a, np.where(rng.integers(0, 2, size=a.shape) == 1, np.inf, -np.inf))
+    return np.where(a == 0.0, a, out)              # keep exact zeros (densities must stay >= 0)
+
+
+def noise_floor(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200, runs=12, seed=0):
+    """Per-pair noise floor of the algorithm itself for (P, N_alt) inputs without a committed fixture: the
+    larger of its response to +-1 ulp on every input (what oracle/gen_golden.py records from the reference
+    for G4/G5/G10) and to +-1 ulp in sin / cos / YT**4 / YT**3 (rounding_noise), ``runs`` evaluations each."""
+    den, bmag, bpsi = (np.atleast_2d(np.asarray(x, dtype=np.float64)) for x in (den, bmag, bpsi))
+    alt = np.asarray(alt, dtype=np.float64)
+    freq = np.atleast_1d(np.asarray(freq_mhz, dtype=np.float64))
+    rng = np.random.default_rng(seed)
+    out = np.zeros((den.shape[0], freq.size))
+    with np.errstate(all="ignore"):
+        for p in range(den.shape[0]):
+            a = alt[p] if alt.ndim == 2 else alt
+            base = virtual_heights(freq, den[p], bmag[p], bpsi[p], a, mode, n_points)
+            worst = rounding_noise(freq, den[p], bmag[p], bpsi[p], a, mode, n_points, runs=runs, seed=seed + p)
+            for _ in range(runs):
+                v = virtual_heights(_ulp_jitter(rng, freq), _ulp_jitter(rng, den[p]), _ulp_jitter(rng, bmag[p]),
+                                    _ulp_jitter(rng, bpsi[p]), _ulp_jitter(rng, a), mode, n_points)
+                both = np.isfinite(v) & np.isfinite(base)
+                rel = np.where(both, np.abs(v - base) / np.abs(np.where(both, base, 1.0)), 0.0)
+                worst = np.maximum(worst, np.where(np.isfinite(v) != np.isfinite(base), np.inf, rel))
+            out[p] = worst
+    return out
 
 
 def virtual_heights_batch(freq_mhz, den, bmag, bpsi, alt, mode="O", n_points=200):

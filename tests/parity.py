@@ -1,15 +1,27 @@
 """Parity rules shared by the GPU tests ("Parity rule").
 
-X mode is well conditioned (reference noise <= 2e-11): plain relative tolerance.
-O mode is ill conditioned near reflection: the reference's own answer moves by up to 8e-5
-under 1-ulp input jitter at a few frequencies per profile, so the rule is noise-aware:
-    |gpu - ref| <= max(1e-6, NOISE_FACTOR * noise_eff) * |ref|   for every finite pair,
-    >= 95 % of finite pairs within 1e-6,
+X mode is well conditioned (reference noise <= 3e-11): plain relative tolerance, 1e-8 (BASELINE asks 1e-4).
+
+O mode is ill conditioned near reflection (D of library.py:229 cancels to 1e-9 of its terms): the reference's
+own answer moves by up to 2e-4 at a few frequencies per profile when its inputs move by one ulp - or when its
+math library rounds sin, cos, YT**4 or YT**3 the other way, which is what any other implementation amounts to.
+The rule is SURVEY.md 8(d)'s, per pair, no smoothing over neighbouring frequencies:
+
+    |gpu - ref| <= max(1e-6, 4 * noise[p, f]) * |ref|      for every finite pair,
+    at least MIN_WITHIN of the finite pairs within 1e-6,
     NaN masks identical,
-where noise is the committed jitter response of the reference itself (oracle/gen_golden.py,
-24 runs) and noise_eff its maximum over a +-2-frequency window of the same profile: the
-response is bimodal (a rounding flip at the last grid points moves the sum by ~1e-6), so a
-pair whose own 24 runs happened not to flip is judged by its neighbours' instability.
+
+with noise[p, f] = max(input noise, rounding noise):
+  * input noise: the REFERENCE re-run 24 times with every input moved by +-1 ulp (oracle/gen_golden.py,
+    committed with fixtures G4, G5, G10);
+  * rounding noise: the pinned oracle (bit-identical to the reference on every fixture) re-run 24 times with
+    the results of sin, cos, YT**4, YT**3 moved by -1/0/+1 ulp (fixture G12; `oracle_noise` computes both
+    kinds on the box for inputs that have no fixture).  The input jitter alone misses it: NumPy's pow is one
+    ulp off the exactly rounded value over whole argument ranges, so jittered inputs do not flip it, while
+    an exactly rounding implementation (prhf_crmath.h) does differ there - measured on G10: 2 of 5401 pairs
+    at 1.4e-6 / 4.2e-6 with an input noise of 1e-11 and a rounding noise of 1.4e-6 / 4.2e-6.
+Round 1 widened the input noise over a +-2-frequency window instead; with the rounding noise in the floor no
+window is needed (tests/devtools/omode_report.py prints the counts for every fixture).
 """
 
 import numpy as np
@@ -17,7 +29,8 @@ import numpy as np
 X_TOL_BASELINE = 1e-4      # BASELINE.json north_star, X mode at high n_points
 X_TOL_TIGHT = 1e-8         # what we actually require
 O_TOL = 1e-6               # BASELINE.json north_star, O mode
-NOISE_FACTOR = 4.0
+NOISE_FACTOR = 4.0         # SURVEY.md 8(d)
+MIN_WITHIN = 0.99          # share of finite O-mode pairs that must meet 1e-6 outright (SURVEY asks 0.95; measured 0.999)
 
 
 def rel_err(got, want):
@@ -29,13 +42,28 @@ def rel_err(got, want):
     return err, ok
 
 
-def effective_noise(noise, half_window=2):
+def effective_noise(noise, half_window=0):
+    """noise with NaN -> inf; half_window > 0 maximises over neighbouring frequencies (diagnostics only)."""
     n = np.where(np.isfinite(noise), noise, np.inf)
     out = n.copy()
     for k in range(1, half_window + 1):
         out[..., k:] = np.maximum(out[..., k:], n[..., :-k])
         out[..., :-k] = np.maximum(out[..., :-k], n[..., k:])
     return out
+
+
+def combined_noise(*floors):
+    out = None
+    for n in floors:
+        n = effective_noise(np.asarray(n, dtype=np.float64))
+        out = n if out is None else np.maximum(out, n)
+    return out
+
+
+def oracle_noise(freq, den, bmag, bpsi, alt, mode, n_points, runs=12, seed=0):
+    """Noise floor for inputs without a fixture, from the pinned oracle on this machine (both kinds)."""
+    from oracle import vfo_numpy as orc
+    return orc.noise_floor(freq, den, bmag, bpsi, alt, mode, n_points, runs=runs, seed=seed)
 
 
 def assert_masks(got, want):
@@ -51,18 +79,21 @@ def assert_x_mode(got, want, tol=X_TOL_TIGHT):
     return float(err.max(initial=0.0))
 
 
-def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR):
+def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WITHIN):
+    """The O-mode rule above.  `noise` None: 1e-6 for every pair."""
     assert_masks(got, want)
     err, ok = rel_err(got, want)
     if noise is None:
         limit = np.full(want.shape, O_TOL)
     else:
-        limit = np.maximum(O_TOL, factor * effective_noise(noise))
+        limit = np.maximum(O_TOL, factor * effective_noise(np.broadcast_to(noise, want.shape)))
     over = ok & (err > limit)
     assert not over.any(), (f"O-mode: {int(over.sum())} pairs beyond max(1e-6, {factor}*noise); worst "
                             f"{err[over].max():.3e} at {np.argwhere(over)[:5].tolist()}")
     n_ok = int(ok.sum())
     if n_ok:
         frac = float((err[ok] <= O_TOL).sum()) / n_ok
-        assert frac >= 0.95, f"only {frac:.3f} of finite pairs within 1e-6"
+        # a handful of pairs cannot support a 1 % statistic: allow one pair per started 100
+        allowed = max(int(np.ceil((1.0 - min_within) * n_ok)), 1 if n_ok < 100 else 0)
+        assert int((err[ok] > O_TOL).sum()) <= allowed, f"only {frac:.4f} of {n_ok} finite pairs within 1e-6"
     return float(err.max(initial=0.0))

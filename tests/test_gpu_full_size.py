@@ -14,7 +14,7 @@ import zlib
 import numpy as np
 import pytest
 
-from parity import assert_masks, assert_x_mode, rel_err
+from parity import assert_masks, assert_o_mode, assert_x_mode, oracle_noise, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -69,11 +69,11 @@ def test_config3_10000_profiles_o_mode(lib):
     assert np.all(vh[fin] > alt.min()) and np.all(vh[fin] < 5000.0)
     # oracle on a random sample
     rng = np.random.default_rng(3)
-    pick = np.sort(rng.choice(10000, size=8, replace=False))
+    pick = np.sort(rng.choice(10000, size=48, replace=False))
     want = orc.virtual_heights_batch(freq, den[pick], bmag[pick], bpsi[pick], alt, "O", 200)
-    assert_masks(vh[pick], want)
-    err, ok = rel_err(vh[pick], want)
-    assert np.mean(err[ok] <= 1e-6) >= 0.95 and err.max() <= 5e-4
+    # per pair against the oracle's own noise floor on this machine (the first 64 rows are fixture G10, with the
+    # reference's recorded floor: tests/test_gpu_parity.py)
+    assert_o_mode(vh[pick], want, oracle_noise(freq, den[pick], bmag[pick], bpsi[pick], alt, "O", 200), min_within=0.995)
 
 
 def test_config4_shard_x_mode_20000(lib):

@@ -1,12 +1,13 @@
 """Randomised parity: many small random problems (non-uniform altitude grids, E-F valleys, plateaus,
 field angles that jump, per-profile altitude rows, ragged frequency sets, every n_points from 1 up,
-both tiers, chunked and unchunked launches) against the plain-C oracle, which is itself pinned to the
-reference's golden vectors (tests/test_oracle_c.py)."""
+both tiers, chunked and unchunked launches).  X mode against the plain-C oracle (pinned to the reference's
+golden vectors at 1e-12, tests/test_oracle_c.py); O mode against the NumPy oracle (bit-identical to the
+reference on every fixture) under the per-pair noise rule of tests/parity.py, the floor computed on the box."""
 
 import numpy as np
 import pytest
 
-from parity import assert_masks, rel_err
+from parity import assert_masks, assert_o_mode, oracle_noise, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +47,7 @@ def random_problem(rng):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_problems_against_c_oracle(seed):
-    from oracle import vfo_c
+    from oracle import vfo_c, vfo_numpy
     from pyrayhf_amd import library
     if not vfo_c.available():
         pytest.skip("oracle/libvfo_oracle.so not built")
@@ -56,23 +57,31 @@ def test_random_problems_against_c_oracle(seed):
         freq, den, bmag, bpsi, alt, n_points = random_problem(rng)
         if np.any(np.argmax(den, axis=1) == 0):
             continue                                      # peak at level 0 is an error path, tested elsewhere
-        for mode in "OX":
-            want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n_points)
-            for tier in (library.MATH_FAITHFUL, library.MATH_FAST):
-                got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=tier)
-                assert got.shape == want.shape
-                assert_masks(got, want)
-                err, ok = rel_err(got, want)
-                if mode == "X":
-                    assert err.max(initial=0.0) <= 1e-7, (seed, mode, tier, n_points, err.max())
-                else:
-                    # O mode is ill conditioned at the last grid points (1 - X ~ 1e-9) and there is no noise floor
-                    # for random inputs (the fixture tests carry them): bound the worst pair loosely and the
-                    # typical pair tightly
-                    assert err.max(initial=0.0) <= 5e-3, (seed, mode, tier, n_points, err.max())
-                    if ok.sum() >= 10:
-                        assert np.median(err[ok]) <= 1e-6, (seed, tier, n_points, np.median(err[ok]))
-                checked += 1
+        want_x = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", n_points)
+        with np.errstate(all="ignore"):
+            want_o = vfo_numpy.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", n_points)
+        noise = oracle_noise(freq, den, bmag, bpsi, alt, "O", n_points, runs=8, seed=seed)
+        for tier in (None, library.MATH_FAITHFUL, library.MATH_FAST):
+            got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n_points, math=tier)
+            assert got.shape == want_x.shape
+            assert_masks(got, want_x)
+            err, ok = rel_err(got, want_x)
+            assert err.max(initial=0.0) <= 1e-7, (seed, "X", tier, n_points, err.max())
+            got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", n_points, math=tier)
+            if tier == library.MATH_FAST:
+                # the reduced algebra everywhere is not parity grade in O mode (opt-in): masks, and the typical pair
+                assert_masks(got, want_o)
+                err, ok = rel_err(got, want_o)
+                assert err.max(initial=0.0) <= 5e-3, (seed, tier, n_points, err.max())
+                if ok.sum() >= 10:
+                    assert np.median(err[ok]) <= 1e-6, (seed, tier, n_points, np.median(err[ok]))
+            else:
+                # the default arithmetic and the reference order everywhere: per pair, max(1e-6, 4 x noise)
+                try:
+                    assert_o_mode(got, want_o, noise, min_within=0.9)
+                except AssertionError as exc:
+                    raise AssertionError(f"seed {seed} tier {tier} n_points {n_points}: {exc}") from None
+            checked += 2
     assert checked > 100
 
 
@@ -99,12 +108,12 @@ def test_non_uniform_grid_at_full_resolution():
         assert_masks(got, want)
         err, ok = rel_err(got, want)
         assert ok.sum() > 500 and err.max() <= 1e-9, err.max()
-        want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", 2000)
-        got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 2000)
-        assert_masks(got, want)
+        from oracle import vfo_numpy
+        want = vfo_numpy.virtual_heights_batch(freq, den[:8], bmag[:8], bpsi[:8], alt, "O", 2000)
+        got = library.vertical_forward_operator(freq, den[:8], bmag[:8], bpsi[:8], alt, "O", 2000)
+        assert_o_mode(got, want, oracle_noise(freq, den[:8], bmag[:8], bpsi[:8], alt, "O", 2000, runs=8))
         err, ok = rel_err(got, want)
-        # no noise floor exists for these inputs: typical pair tight, worst (cusp) pair loose, as above
-        assert np.median(err[ok]) <= 1e-9 and err.max() <= 5e-3, (np.median(err[ok]), err.max())
+        assert np.median(err[ok]) <= 1e-9
 
 
 @pytest.mark.parametrize("n_alt", [700, 1400])
