@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the vertical-ionogram forward operator on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config5]
 
 A "step" is one pass of the hot path over one device-resident batch of synthetic profiles:
 one fused-kernel launch per GPU (plus, for N > 1, the gather of the result rows over RCCL).
-Workload (DESIGN.md "Measurement"): the per-GPU shard of BASELINE.json configs[3] - the
-configuration its target "virtual-height integrals/s at n_points=20000 X-mode" is quoted on -
-12 500 synthetic Chapman profiles x 256 frequencies, X mode, n_points = 20000 per GPU, so
-that N = 8 is exactly config 4 (weak scaling).  The single-profile configs[1] (latency-bound:
-174 pairs per launch) is timed too and reported under "single_profile".
 
+Workloads (DESIGN.md "Measurement"; always the rows rank r would own at N = 8, so N = 8 is the
+BASELINE configuration itself and smaller N are weak-scaling prefixes of it):
+  config4 (default)  per-GPU shard of BASELINE.json configs[3] - the configuration its target
+                     "integrals/s at n_points=20000 X-mode" is quoted on: 12 500 synthetic Chapman
+                     profiles x 256 frequencies, X mode, n_points = 20000 per GPU;
+  config3            configs[2]: 10 000 profiles x 174 frequencies, O mode, n_points = 200 (per GPU);
+  config5            per-GPU shard of configs[4]: 6 250 profiles x 512 frequencies, mixed O/X x
+                     n_points in {200, 2000, 20000}, ONE work-list launch per GPU.
+The single-profile configs[1] (latency-bound: 174 pairs per launch) is timed too and reported under
+"single_profile".
+
+Launch: `python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed.run
+on 127.0.0.1) when it is not already running under a launcher; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it is given.
 Rank 0 prints ONE JSON line.  `value` counts every submitted (profile, frequency) pair; the
 reflecting fraction is reported beside it.  Inputs are resident in HBM before the timed region.
 """
@@ -20,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,56 +41,143 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X public spec, vector FP64 (the bound that binds)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 = 1/2 of the guide's 157.3 TFLOP/s vector FP32
 FLOPS_PER_POINT = 68           # CSE'd nominal FP64 operations per grid point
 FLOPS_PER_LEVEL = 6            # reflection search, per bottomside level and pair
 
+CONFIG5_SEGMENTS = [(0, 20000, "O", 200), (20000, 35000, "X", 2000), (35000, 45000, "O", 2000),
+                    (45000, 50000, "X", 20000)]      # BASELINE configs[4], SURVEY.md 8d
 
-def algorithmic_bytes(n_prof, n_alt, n_freq, n_points, per_profile_alt=False):
-    """Compulsory HBM traffic of one launch."""
-    return 8 * (3 * n_prof * n_alt + n_alt * (n_prof if per_profile_alt else 1) + n_freq + n_points
+
+def algorithmic_bytes(n_prof, n_alt, n_freq, grid_points, per_profile_alt=False):
+    """Compulsory HBM traffic of one launch; grid_points = sum of the launch's n_points."""
+    return 8 * (3 * n_prof * n_alt + n_alt * (n_prof if per_profile_alt else 1) + n_freq + grid_points
                 + n_prof * n_freq)
 
 
-def algorithmic_flops(vh, den, n_points):
+def algorithmic_flops(vh, den, n_points_per_row):
     """68 * n_points per reflecting pair + 6 * K per pair."""
     k = np.argmax(den, axis=1).astype(np.float64)
     reflecting = np.isfinite(vh).sum(axis=1).astype(np.float64)
-    return float((FLOPS_PER_POINT * n_points * reflecting).sum() + (FLOPS_PER_LEVEL * k * vh.shape[1]).sum())
+    return float((FLOPS_PER_POINT * np.asarray(n_points_per_row, dtype=np.float64) * reflecting).sum()
+                 + (FLOPS_PER_LEVEL * k * vh.shape[1]).sum())
 
 
-def cpu_baseline(freq, alt, den, bmag, bpsi, mode, n_points, budget_s=20.0):
-    """The oracle (NumPy restatement of the reference's CPU path) on a bounded sample."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = the reference's algorithm; reported beside the GPU number, not a target)
+# ------------------------------------------------------------------------------------------------
+def usable_cores():
+    """Host cores this process may use: the affinity mask, capped by the cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_worker(job):
+    """One worker process of the all-cores leg: NumPy oracle on its own rows until the budget is spent."""
+    freq, alt, den, bmag, bpsi, mode, n_points, budget_s = job
     from oracle import vfo_numpy as orc
     done, t0 = 0, time.perf_counter()
-    orc.virtual_heights(freq, den[0], bmag[0], bpsi[0], alt, mode, min(n_points, 200))   # import/warm-up
-    t0 = time.perf_counter()
     while done < den.shape[0]:
         orc.virtual_heights(freq, den[done], bmag[done], bpsi[done], alt, mode, n_points)
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(freq, alt, den, bmag, bpsi, mode, n_points, what, budget_s=10.0):
+    """The oracle (NumPy restatement of the reference's CPU path), one process, on a bounded sample."""
+    from oracle import vfo_numpy as orc
+    orc.virtual_heights(freq, den[0], bmag[0], bpsi[0], alt, mode, min(n_points, 200))   # import / warm-up
+    done, dt = _cpu_worker((freq, alt, den, bmag, bpsi, mode, n_points, budget_s))
     return {"value": done * freq.size / dt, "unit": "integrals/s", "cores": 1, "kind": "port",
-            "sample": f"{done} profiles x {freq.size} freqs, {mode}-mode n_points={n_points}, "
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+            "sample": f"{done} profiles x {freq.size} freqs of {what}, {mode}-mode n_points={n_points}, "
                       f"oracle/vfo_numpy.py single process, {dt:.1f} s"}
 
 
-def cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points):
-    """The fused plain-C restatement (oracle/vfo_oracle.c) on every host core: a stronger
-    CPU baseline than the reference's unfused NumPy path.  None when the library is not built."""
+def cpu_baseline_all_cores(freq, alt, den, bmag, bpsi, mode, n_points, what, budget_s=8.0):
+    """the same oracle under multiprocessing over profiles on every usable host core."""
+    import multiprocessing as mp
+    cores = usable_cores()
+    per = max(1, den.shape[0] // cores)
+    jobs = [(freq, alt, den[i * per:(i + 1) * per], bmag[i * per:(i + 1) * per], bpsi[i * per:(i + 1) * per], mode,
+             n_points, budget_s) for i in range(cores) if den[i * per:(i + 1) * per].shape[0]]
+    # spawn: the workers must not inherit this process's GPU state; they import numpy and oracle/ only
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        pool.map(_cpu_worker, [(freq, alt, den[:1], bmag[:1], bpsi[:1], mode, min(n_points, 200), 0.0)] * len(jobs))
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
+        wall = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    return {"value": done * freq.size / wall, "unit": "integrals/s", "cores": len(jobs), "kind": "port",
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
+            "sample": f"{done} profiles x {freq.size} freqs of {what}, {mode}-mode n_points={n_points}, "
+                      f"oracle/vfo_numpy.py in {len(jobs)} processes (multiprocessing, one per usable core), {wall:.1f} s"}
+
+
+def cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points, what):
+    """The fused plain-C restatement (oracle/vfo_oracle.c) on every usable core: a stronger CPU baseline than
+    the reference's unfused NumPy path.  None when the library is not built."""
     from oracle import vfo_c
     if not vfo_c.available():
         return None
-    cores = min(vfo_c.threads(), 16)          # the GPU box's CPU share for one GPU
+    cores = min(vfo_c.threads(), usable_cores())
     vfo_c.virtual_heights_batch(freq, den[:cores], bmag[:cores], bpsi[:cores], alt, mode, 200, n_threads=cores)
     n = min(den.shape[0], 4 * cores)
     t0 = time.perf_counter()
     vfo_c.virtual_heights_batch(freq, den[:n], bmag[:n], bpsi[:n], alt, mode, n_points, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": n * freq.size / dt, "unit": "integrals/s", "cores": cores, "kind": "port",
-            "sample": f"{n} profiles x {freq.size} freqs, {mode}-mode n_points={n_points}, "
+            "sample": f"{n} profiles x {freq.size} freqs of {what}, {mode}-mode n_points={n_points}, "
                       f"oracle/vfo_oracle.c OpenMP x{cores}, {dt:.1f} s"}
+
+
+def config5_segments(world, profiles_per_gpu=None):
+    """The global work list of an N-GPU run: the first N/8 of every slice of BASELINE config 5 (N = 8: all of
+    it), optionally scaled to `profiles_per_gpu` rows per GPU in the same proportions (rehearsals)."""
+    segs = [(p0, p0 + ((p1 - p0) * world) // 8, m, n) for (p0, p1, m, n) in CONFIG5_SEGMENTS]
+    if profiles_per_gpu:
+        f = profiles_per_gpu * world / sum(p1 - p0 for p0, p1, _, _ in segs)
+        segs = [(p0, p0 + max(1, int((p1 - p0) * f)), m, n) for (p0, p1, m, n) in segs]
+    return segs
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) and wait.
+
+    This parent never touches the GPU (no torch.cuda call, no libprhf): the ranks are fresh child
+    processes of `python -m torch.distributed.run`, whose stdout (rank 0's JSON line) passes through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this image)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -87,14 +185,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--profiles", type=int, default=12500, help="profiles per GPU")
-    ap.add_argument("--freqs", type=int, default=256)
-    ap.add_argument("--n-points", type=int, default=20000)
-    ap.add_argument("--mode", default="X", choices=["O", "X"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5"])
+    ap.add_argument("--profiles", type=int, default=None, help="profiles per GPU (default: the workload's)")
+    ap.add_argument("--freqs", type=int, default=None)
+    ap.add_argument("--n-points", type=int, default=None)
+    ap.add_argument("--mode", default=None, choices=["O", "X"])
     ap.add_argument("--math", default=None, choices=[None, "faithful", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-profile", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -104,8 +206,6 @@ def main():
 
     rank, world, local_rank = pdist.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists in the product path)")
@@ -114,6 +214,9 @@ def main():
     backend = os.environ.get("PRHF_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPUs are visible "
+                         "(PRHF_BENCH_BACKEND=gloo rehearses N ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -122,20 +225,66 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    world_seen = dist.get_world_size() if world > 1 else 1
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
-    p_gpu, n_freq, n_points, mode = args.profiles, args.freqs, args.n_points, args.mode
-    p_total = p_gpu * world
-    freq = np.linspace(0.5, 16.0, n_freq)                       # config 4 sweep
-    lo, hi = pdist.shard_bounds(p_total, world, rank)
-    # always the rows of config 4's 100 000-profile draw: N = 1 is its first shard, N = 8 the whole of it
-    alt, den, bmag, bpsi = synth.chapman_profiles(max(p_total, 100000), 20260004, rows=slice(lo, hi))
+    ctx = _native.context(local_rank)
+
+    # ---- the workload: this rank's rows of the BASELINE configuration ------------------------------
+    if args.workload == "config5":
+        n_freq = args.freqs or 512
+        freq = np.linspace(0.5, 16.0, n_freq)
+        # N GPUs take the first N/8 of every slice of config 5; rank r its shard_bounds block of each
+        global_segs = config5_segments(world, args.profiles)
+        rows, local_segs = pdist.shard_segments(global_segs, world, rank)
+        alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=rows)
+        p_gpu = int(rows.size)
+        p_total = sum(p1 - p0 for p0, p1, _, _ in global_segs)
+        n_points_row = np.concatenate([np.full(p1 - p0, n) for p0, p1, _, n in local_segs])
+        grid_points = sum(n for _, _, _, n in local_segs)
+        mode, n_points = "mixed", 0
+        what = "BASELINE configs[4] (50000 x 512 mixed work list)"
+        workload = (f"BASELINE configs[4] per-GPU shard: {p_gpu} synthetic Chapman profiles x {n_freq} freqs (0.5-16 MHz) "
+                    f"per GPU in one work-list launch, slices " +
+                    ", ".join(f"{p1 - p0} x {m}/{n}" for p0, p1, m, n in local_segs) +
+                    ", seed 20260005; N=8 is config 5 (50000 x 512)")
+    else:
+        c3 = args.workload == "config3"
+        p_gpu = args.profiles or (10000 if c3 else 12500)
+        n_freq = args.freqs or (174 if c3 else 256)
+        n_points = args.n_points or (200 if c3 else 20000)
+        mode = args.mode or ("O" if c3 else "X")
+        freq = synth.sounder_frequencies(3) if (c3 and n_freq == 174) else np.linspace(0.5, 16.0, n_freq)
+        p_total = p_gpu * world
+        lo, hi = pdist.shard_bounds(p_total, world, rank)
+        if c3:      # config 3 is a one-GPU configuration: N ranks = N independent draws of its size (replicas)
+            alt, den, bmag, bpsi = synth.chapman_profiles(p_total, 20260003, rows=slice(lo, hi))
+            what = "BASELINE configs[2] (10000 x 174, O/200)"
+            workload = (f"BASELINE configs[2]: {p_gpu} synthetic Chapman profiles x {n_freq} freqs per GPU, {mode}-mode, "
+                        f"n_points={n_points}, seed 20260003")
+        else:       # always the rows of config 4's 100 000-profile draw: N = 1 is its first shard, N = 8 all of it
+            alt, den, bmag, bpsi = synth.chapman_profiles(max(p_total, 100000), 20260004, rows=slice(lo, hi))
+            what = "BASELINE configs[3] (100000 x 256, X/20000)"
+            workload = (f"BASELINE configs[3] per-GPU shard: {p_gpu} synthetic Chapman profiles x {n_freq} freqs "
+                        f"(0.5-16 MHz) per GPU, {mode}-mode, n_points={n_points}, seed 20260004; N=8 is config 4 "
+                        f"(100000 x 256)")
+        n_points_row = np.full(p_gpu, n_points)
+        grid_points = n_points
+        local_segs = global_segs = None
+
     t = {k: torch.as_tensor(v, device=dev) for k, v in
          (("freq", freq), ("alt", alt), ("den", den), ("bmag", bmag), ("bpsi", bpsi))}
     out = torch.empty((p_gpu, n_freq), dtype=torch.float64, device=dev)
-    ctx = _native.context(local_rank)
 
     def step():
+        nonlocal out
+        if local_segs is not None:
+            out = library.vertical_forward_operator_mixed(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"],
+                                                          local_segs, math=math)
+            ms = ctx.last_kernel_ms()
+            if world > 1:
+                pdist.gather_mixed(out, global_segs, max(p1 for _, p1, _, _ in global_segs))
+            return ms
         library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], mode, n_points,
                                           math=math, sync=False, out=out)
         ms = ctx.last_kernel_ms()            # HIP events on the launch stream, recorded by the library
@@ -162,20 +311,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    result = None
     if rank == 0:
         vh = out.cpu().numpy()
         ms_step = 1e3 * elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
-        abytes = algorithmic_bytes(p_gpu, alt.size, n_freq, n_points)
-        aflops = algorithmic_flops(vh, den, n_points)
-        traffic = None
+        abytes = algorithmic_bytes(p_gpu, alt.size, n_freq, grid_points)
+        aflops = algorithmic_flops(vh, den, n_points_row)
+        traffic, traffic_src = None, None
         prof_json = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof_json):
             with open(prof_json) as fh:
                 rec = json.load(fh)
             key = f"{mode}_{n_points}_{p_gpu}x{n_freq}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            if key in rec:
+                traffic = rec[key].get("hbm_bytes_per_launch")
+                traffic_src = (f"NOT measured in this run: replayed from profiles/hbm_traffic.json[{key}] "
+                               f"(rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of this workload, {rec[key].get('source')})")
+        default_tier = _native.MATH_FAST if (mode == "X" and math is None) else (math if math is not None
+                                                                                  else _native.MATH_FAITHFUL)
         result = {
             "metric": "virtual-height integrals/s (profile x frequency pairs)",
             "value": p_total * n_freq * args.steps / elapsed,
@@ -187,15 +340,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3] per-GPU shard: {p_gpu} synthetic Chapman profiles x "
-                                   f"{n_freq} freqs (0.5-16 MHz) per GPU, {mode}-mode, n_points={n_points}, "
-                                   f"seed 20260004; N=8 is config 4 (100000 x 256)",
-                       "profiles_per_gpu": p_gpu, "n_freq": n_freq, "n_points": n_points, "mode": mode,
-                       "n_alt": int(alt.size), "math": args.math or "default",
-                       "parallelism": f"profile shards x{world}, all_gather of vh rows" if world > 1 else "single GPU"},
+            "config": {"workload": workload,
+                       "profiles_per_gpu": p_gpu, "n_freq": n_freq, "n_points": n_points or "200/2000/20000",
+                       "mode": mode, "n_alt": int(alt.size), "math": args.math or "default",
+                       "parallelism": (f"profile shards x{world}, one process per GPU, all_gather of vh rows over "
+                                       f"{'RCCL' if backend == 'nccl' else backend}") if world > 1 else "single GPU"},
+            "world_size_seen": world_seen, "backend": backend if world > 1 else None,
             "reflecting_fraction": float(np.isfinite(vh).mean()),
-            "workgroups_per_cu": ctx.occupancy(alt.size, _native.MATH_FAST if mode == "X" and math is None
-                                               else (math or _native.MATH_FAITHFUL)),
+            "workgroups_per_cu": ctx.occupancy(alt.size, default_tier),
             "kernel_ms": k_ms,
             # the FP64 vector ALU (not MFMA, not HBM) binds this path, so the primary
             # roofline object prices the nominal 68 flop/point against the 78.6 TFLOP/s vector peak;
@@ -203,12 +355,13 @@ def main():
             "roofline": {"bound": "fp64_valu", "achieved": aflops / (k_ms * 1e-3) / 1e12,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": aflops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_point": FLOPS_PER_POINT,
-                         "note": "non-MFMA FP64 vector roofline (SURVEY 8d); traffic = measured HBM bytes/launch"},
+                         "note": "non-MFMA FP64 vector roofline (SURVEY 8d): nominal 68 flop/point x reflecting points "
+                                 "+ 6 flop/level/pair, over the fused kernel's HIP-event time on this rank"},
             "roofline_hbm": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic, "algorithmic_bytes": abytes,
+                             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": abytes,
                              "note": "compulsory bytes only; the fused kernel is not HBM bound by construction"},
         }
 
@@ -230,7 +383,7 @@ def main():
                                         "ms_per_call": 1e3 * dt1, "integrals_per_s": f1.size / dt1,
                                         "kernel_ms": ctx.last_kernel_ms()}
 
-        if world == 1 and not args.no_single_profile:
+        if world == 1 and not args.no_single_profile and local_segs is None:
             # the same batch handed over as host NumPy buffers (pageable): H2D + kernel + D2H
             # first call: the library's staging arena grows to this batch (hipMalloc); second call: steady state
             library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
@@ -241,8 +394,20 @@ def main():
                                       "note": "PCIe-inclusive (pageable host memory in and out); never `value`"}
 
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(freq, alt, den[:64], bmag[:64], bpsi[:64], mode, n_points)   # ~20 s
-            result["cpu_baseline_fused_c"] = cpu_baseline_c(freq, alt, den, bmag, bpsi, mode, n_points)
+            # bounded samples of the same workload (for config 5: its X/20000 slice, where the CPU time goes)
+            if local_segs is not None:
+                p0, p1, b_mode, b_n = local_segs[-1]
+                sel = slice(p0, p1)
+            else:
+                b_mode, b_n, sel = mode, n_points, slice(0, p_gpu)
+            d, b, p = den[sel], bmag[sel], bpsi[sel]
+            result["cpu_baseline"] = cpu_baseline(freq, alt, d[:512], b[:512], p[:512], b_mode, b_n, what)
+            try:
+                result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(freq, alt, d[:2048], b[:2048], p[:2048],
+                                                                          b_mode, b_n, what)
+            except Exception as exc:       # noqa: BLE001 - a sandbox without process spawning must not sink the GPU line
+                result["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"}
+            result["cpu_baseline_fused_c"] = cpu_baseline_c(freq, alt, d, b, p, b_mode, b_n, what)
         print(json.dumps(result), flush=True)
 
     if world > 1:

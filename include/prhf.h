@@ -14,7 +14,9 @@
  *     PRHF_FLAG_ASYNC, until the next prhf_sync on that context) and owns nothing but its
  *     context (stream, scratch, events);
  *   - a context is bound to one device and is not thread-safe; different contexts are
- *     independent and may be used from different threads.
+ *     independent and may be used from different threads;
+ *   - every entry point runs on its context's device and restores the calling thread's current
+ *     HIP device before it returns (a process that drives several GPUs keeps its own current device).
  *
  * Units are the reference's (library.py:465-474): freq MHz, den m^-3, bmag Tesla,
  * bpsi degrees, alt km; the result is virtual height in km, NaN where the sounder
@@ -33,7 +35,7 @@ extern "C" {
 
 /* return codes */
 #define PRHF_OK        0
-#define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination */
+#define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination, bad segment or index */
 #define PRHF_ENEGDEN  -2   /* a density below the peak is negative (reference library.py:93-94 raises ValueError) */
 #define PRHF_EPEAK0   -3   /* density peak at index 0: empty bottomside (the reference raises IndexError) */
 #define PRHF_EHIP     -4   /* HIP runtime failure; message carries hipGetErrorString */
@@ -62,7 +64,10 @@ typedef struct prhf_ctx prhf_ctx;
 /* One homogeneous slice of a mixed launch (BASELINE config 5): profiles [prof_begin, prof_end)
  * are evaluated with one mode and one grid size.  mult_offset indexes the concatenated
  * multiplier array; the slice's output rows start at vh_out + out_offset (row-major
- * (prof_end - prof_begin, n_freq)). */
+ * (prof_end - prof_begin, n_freq)).  out_offset must be a non-negative multiple of n_freq and the
+ * output rows of two segments must not overlap (PRHF_EINVAL otherwise).  With host buffers, output rows
+ * below the highest written row that no segment covers come back as NaN; with device pointers the
+ * library writes only the rows its segments cover. */
 typedef struct prhf_segment {
     int64_t prof_begin;
     int64_t prof_end;
@@ -190,7 +195,9 @@ int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
  * reference's dict entries; its x_apex_km / z_apex_km equal the midpoint), then x and z of the turning
  * point and the number of path nodes.  Rays that never turn give NaN (node count 0).  path_x / path_z
  * (optional, (n_rays, path_stride), path_stride >= 2 n_alt + 1) receive the reference's 'x' and 'z'
- * arrays padded with NaN.  Synchronous; PRHF_ENEGDEN on a negative density.
+ * arrays padded with NaN.  Synchronous; PRHF_ENEGDEN on a negative density; PRHF_EINVAL when a
+ * profile_index lies outside [0, n_prof) - checked on the host for host buffers and by the kernel for
+ * device-resident ones (that ray's outputs are NaN, no memory outside the columns is read).
  */
 int prhf_snell_cartesian_f64(prhf_ctx* ctx, const double* freq_hz, const double* elevation_deg,
                              const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,

@@ -253,6 +253,15 @@ def default_device():
     return 0
 
 
+def host_context(device=None):
+    """The cached context, launching on its OWN stream: what every host-buffer (NumPy) call uses.  A
+    previous torch call on this thread may have left the context on torch's stream (borrowed); a host
+    call must not keep running there - that stream may be the legacy blocking one, or already destroyed."""
+    ctx = context(device)
+    ctx.set_stream(0, borrow=False)
+    return ctx
+
+
 def context(device=None):
     """Per-thread, per-device cached context."""
     dev = default_device() if device is None else int(device)

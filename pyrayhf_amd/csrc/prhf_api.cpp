@@ -53,6 +53,33 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Every entry point works on its context's device and leaves the calling thread's current HIP device as it
+// found it (torch's current device is the same per-thread state: a library call must not move it).
+class DeviceScope {
+  public:
+    explicit DeviceScope(int device) {
+        err_ = hipGetDevice(&prev_);
+        if (err_ == hipSuccess && prev_ != device) {
+            err_ = hipSetDevice(device);
+            switched_ = err_ == hipSuccess;
+        }
+    }
+    ~DeviceScope() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+    hipError_t error() const { return err_; }
+
+  private:
+    int prev_ = -1;
+    bool switched_ = false;
+    hipError_t err_ = hipSuccess;
+};
+#define ENTER_DEVICE(dev)            \
+    DeviceScope device_scope_(dev);  \
+    HIP_TRY(device_scope_.error())
+
 }  // namespace
 
 struct prhf_ctx {
@@ -138,6 +165,7 @@ int status_to_code(unsigned bits) {
     if (bits & PRHF_STATUS_PEAK0)
         return fail(PRHF_EPEAK0, "density peak at index 0: no bottomside levels below the peak");
     if (bits & PRHF_STATUS_NEGDEN) return fail(PRHF_ENEGDEN, "Density must be non-negative");
+    if (bits & PRHF_STATUS_BADINDEX) return fail(PRHF_EINVAL, "profile_index outside [0, n_prof)");
     return PRHF_OK;
 }
 
@@ -164,7 +192,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
         return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
 
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
 
     prhf::KArgs a;
     std::memset(&a, 0, sizeof a);
@@ -185,7 +213,14 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if (u.n_points < 1) return fail(PRHF_EINVAL, "n_points must be >= 1");
         if (u.mult_offset < 0 || u.mult_offset + u.n_points > mult_len)
             return fail(PRHF_EINVAL, "segment %d: multiplier range outside the array", i);
-        if (u.out_offset < 0) return fail(PRHF_EINVAL, "segment %d: negative output offset", i);
+        if (u.out_offset < 0 || u.out_offset % n_freq != 0)
+            return fail(PRHF_EINVAL, "segment %d: output offset must be a non-negative multiple of n_freq", i);
+        for (int k = 0; k < i; ++k) {          // rows [out_offset / n_freq, + profiles) of two segments must not overlap
+            const long long a0 = segs[k].out_offset / n_freq, a1 = a0 + (segs[k].prof_end - segs[k].prof_begin);
+            const long long b0 = u.out_offset / n_freq, b1 = b0 + (u.prof_end - u.prof_begin);
+            if (a0 < b1 && b0 < a1 && a0 < a1 && b0 < b1)
+                return fail(PRHF_EINVAL, "segments %d and %d write the same output rows", k, i);
+        }
         prhf::SegDev& s = a.seg[i];
         s.prof_begin = u.prof_begin;
         s.prof_end = u.prof_end;
@@ -300,6 +335,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         }
         a.freq = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.mult = d_mult;
         a.out = d_out;
+        // rows that no segment covers must come back as NaN, not as whatever the arena held (all-ones bytes = NaN)
+        long long covered = 0;
+        for (int i = 0; i < n_segs; ++i) covered += segs[i].prof_end - segs[i].prof_begin;
+        if (covered < out_rows && out_elems) HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_elems * 8, c->stream));
         a.prof_stride = n_alt;
         a.alt_stride = alt_stride ? n_alt : 0;
     }
@@ -419,7 +458,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(PRHF_EINVAL, "device %d not in [0, %d)", device, n);
-    HIP_TRY(hipSetDevice(device));
+    ENTER_DEVICE(device);
     prhf_ctx* c = new (std::nothrow) prhf_ctx;
     if (!c) return fail(PRHF_ENOMEM, "out of host memory");
     c->device = device;
@@ -447,7 +486,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
 
 int prhf_ctx_destroy(prhf_ctx* c) {
     if (!c) return PRHF_OK;
-    (void)hipSetDevice(c->device);
+    DeviceScope device_scope_(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->arena.p) (void)hipFree(c->arena.p);
     if (c->partial.p) (void)hipFree(c->partial.p);
@@ -470,8 +509,11 @@ int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream, int32_t borrow) {
     // a borrowed NULL is the legacy default stream (what torch reports for its default stream)
     hipStream_t next = borrow ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
     if (next == c->stream) return PRHF_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // scratch buffers are reused across launches
+    ENTER_DEVICE(c->device);
+    // Scratch buffers are reused across launches: work on the new stream must come after the last launch on
+    // the old one.  Ordered through the event recorded behind that launch, not by synchronising the old
+    // stream - a borrowed stream may have been destroyed by its owner since.
+    if (c->timed) HIP_TRY(hipStreamWaitEvent(next, c->ev1, 0));
     c->stream = next;
     return PRHF_OK;
 }
@@ -533,7 +575,7 @@ int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double*
     if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "Mode must be O or X");
     if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
     if (n == 0) return PRHF_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     const double *dX = X, *dY = Y, *dP = psi_deg;
     double *dMu = mu_out, *dMup = mup_out;
@@ -569,7 +611,7 @@ int prhf_find_vh_f64(prhf_ctx* c, const double* X, const double* Y, const double
     if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "Mode must be O or X");
     if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
     if (n_rows == 0) return PRHF_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     const int64_t n = n_rows * n_cols;
     const double *dX = X, *dY = Y, *dP = psi_deg, *dD = dh;
@@ -606,7 +648,7 @@ int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const do
     if (n_freq < 1 || n_alt < 1 || n_alt > kMaxAlt || n_points < 1) return fail(PRHF_EINVAL, "bad shape");
     if (mode != PRHF_MODE_O && mode != PRHF_MODE_X) return fail(PRHF_EINVAL, "mode must be 'O' or 'X'");
     if (flags & ~PRHF_FLAG_DEVICE_PTRS) return fail(PRHF_EINVAL, "unknown flag bits");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     const size_t fn = (size_t)n_freq * (size_t)n_points;
     prhf::RegridArgs a;
@@ -669,7 +711,7 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
     if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
         return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
     if (n_prof == 0) return PRHF_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     const size_t pf = (size_t)n_prof * (size_t)n_freq;
     const double *dM = vh_model, *dO = vh_obs;
     double *dR = residual_out, *dC = cost_out;
@@ -722,7 +764,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         for (int64_t r = 0; r < n_rays; ++r)
             if (profile_index[r] < 0 || profile_index[r] >= n_prof)
                 return fail(PRHF_EINVAL, "profile_index[%lld] outside [0, n_prof)", (long long)r);
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     prhf::SnellArgs a;
     std::memset(&a, 0, sizeof a);
     a.n_rays = n_rays; a.n_alt = n_alt; a.prof_stride = n_alt; a.alt_stride = alt_stride_elems;
@@ -817,7 +859,7 @@ int prhf_snell_spherical_f64(prhf_ctx* c, const double* freq_hz, const double* e
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {
     if (!c || !workgroups_per_cu) return fail(PRHF_EINVAL, "null pointer");
     if (n_alt < 1 || n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt out of range");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     int n = 0;
     HIP_TRY(prhf::query_occupancy(math, prhf::lds_bytes_for(n_alt), &n));
     *workgroups_per_cu = n;
@@ -826,7 +868,7 @@ int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups
 
 int prhf_sync(prhf_ctx* c) {
     if (!c) return fail(PRHF_EINVAL, "null context");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     if (c->status_pending) {
         HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(unsigned), c->stream));
@@ -842,7 +884,7 @@ int prhf_sync(prhf_ctx* c) {
 int prhf_last_kernel_ms(prhf_ctx* c, double* ms) {
     if (!c || !ms) return fail(PRHF_EINVAL, "null pointer");
     if (!c->timed) return fail(PRHF_EINVAL, "no launch has been timed on this context");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     HIP_TRY(hipEventSynchronize(c->ev1));
     float t = 0.f;
     HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));

@@ -11,6 +11,7 @@
 
 #define PRHF_STATUS_NEGDEN 0x1
 #define PRHF_STATUS_PEAK0  0x2
+#define PRHF_STATUS_BADINDEX 0x4    // a ray's profile_index outside [0, n_prof) (tracers)
 
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile

@@ -62,7 +62,7 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
     residual = np.empty((n_prof, f.size), dtype=np.float64)
     cost = np.empty(n_prof, dtype=np.float64)
     vh = np.empty((n_prof, f.size), dtype=np.float64) if return_vh else None
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     ctx.set_math(MATH_AUTO if math is None else int(math))
     # one call: candidates staged once, modeled traces stay in HBM between the two kernels
     _native.raise_for(ctx.vfo_residual(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data,

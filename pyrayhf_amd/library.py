@@ -110,7 +110,7 @@ def find_mu_mup(X, Y, bpsi, mode, *, device=None, math=None):
     x, y, p = (np.ascontiguousarray(a).reshape(-1) for a in (X, Y, bpsi))
     mu = np.empty(x.size, dtype=np.float64)
     mup = np.empty(x.size, dtype=np.float64)
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     ctx.set_math(MATH_FAITHFUL if math is None else int(math))
     _native.raise_for(ctx.mu_mup(x.ctypes.data, y.ctypes.data, p.ctypes.data, x.size, _MODE_CODE[mode],
                                  mu.ctypes.data, mup.ctypes.data, 0))
@@ -130,7 +130,7 @@ def find_vh(X, Y, bpsi, dh, alt_min, mode, *, device=None, math=None):
         raise ValueError("X, Y, bpsi and dh must be 2-D (frequencies x grid points)")
     x, y, p, d = (np.ascontiguousarray(a) for a in (X, Y, bpsi, dh))
     vh = np.empty(x.shape[0], dtype=np.float64)
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     ctx.set_math(MATH_FAITHFUL if math is None else int(math))
     _native.raise_for(ctx.find_vh(x.ctypes.data, y.ctypes.data, p.ctypes.data, d.ctypes.data, x.shape[0],
                                   x.shape[1], alt_min, _MODE_CODE[mode], vh.ctypes.data, 0))
@@ -155,7 +155,7 @@ def regrid_to_nonuniform_grid(f, n_e, b, bpsi, aalt, mode='O', n_points=200, dh=
     names = ("freq", "den", "bmag", "bpsi", "dist", "alt", "crit_height")
     out = {k: np.empty(shape, dtype=np.float64) for k in names}
     out["ind"] = np.empty(shape, dtype=np.int64)
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     rc = ctx.regrid(fz.ctypes.data, fz.size, d.ctypes.data, bb.ctypes.data, p.ctypes.data, a.ctypes.data, d.size,
                     mult.ctypes.data, int(n_points), code, [out[k].ctypes.data for k in names + ("ind",)], 0)
     _native.raise_for(rc)
@@ -211,7 +211,7 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     alt_stride = n_alt if a.ndim == 2 else 0
     mult = _multiplier(n_points)
     out = np.empty((n_prof, f.size), dtype=np.float64)
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                        n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
@@ -336,7 +336,7 @@ def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, dev
     out = np.full((n_prof, f.size), np.nan, dtype=np.float64)
     if not segs:
         return out
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     ctx.set_math(_default_math(None, math))       # MATH_AUTO: each slice in its mode's tier, one launch
     # the library writes only the rows its segments cover: stage `out` through the call
     rc = ctx.vfo_worklist(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,

@@ -44,7 +44,7 @@ def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, p
     stride = 2 * n_alt + 1
     px = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
     pz = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
-    ctx = _native.context(device)
+    ctx = _native.host_context(device)
     common = (f.ctypes.data, e.ctypes.data, idx.ctypes.data if idx is not None else None, f.size, d2.ctypes.data,
               b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof, n_alt, n_alt if a.ndim == 2 else 0,
               _native.MODE_O if mode == "O" else _native.MODE_X)

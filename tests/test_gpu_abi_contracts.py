@@ -1,0 +1,110 @@
+"""Contracts of the C ABI that only show on a GPU: segment validation, NaN rows of uncovered output,
+the caller's current device, stream hand-back, and the device-side profile-index check of the tracers."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _worklist(ctx, g, segs, n_rows_out, n_prof=24):
+    from pyrayhf_amd import _native, library
+    f = np.ascontiguousarray(g["freq"][:32])
+    d, b, p = (np.ascontiguousarray(g[k][:n_prof]) for k in ("den", "bmag", "bpsi"))
+    grids = [library._multiplier(s.n_points) for s in segs]
+    mult = np.ascontiguousarray(np.concatenate(grids))
+    out = np.full((n_rows_out, f.size), -7.0)
+    rc = ctx.vfo_worklist(f.ctypes.data, f.size, d.ctypes.data, b.ctypes.data, p.ctypes.data, g["alt"].ctypes.data,
+                          n_prof, d.shape[1], d.shape[1], 0, mult.ctypes.data, mult.size, segs, out.ctypes.data, 0)
+    return rc, out, _native.last_error()
+
+
+def test_worklist_rejects_misaligned_and_overlapping_output_ranges():
+    from pyrayhf_amd import _native
+    g = load_golden("g5_chapman64.npz")
+    ctx = _native.host_context(0)
+    S = _native.Segment
+    # an offset that is not a multiple of n_freq would under-size the staged output
+    rc, _, msg = _worklist(ctx, g, [S(0, 4, _native.MODE_X, 200, 0, 5)], 8)
+    assert rc == _native.EINVAL and "multiple of n_freq" in msg
+    # two segments writing rows 2..5 and 4..7
+    rc, _, msg = _worklist(ctx, g, [S(0, 4, _native.MODE_X, 200, 0, 2 * 32), S(4, 8, _native.MODE_X, 200, 200, 4 * 32)], 8)
+    assert rc == _native.EINVAL and "same output rows" in msg
+    # disjoint ranges with a gap: rows 0..3 and 6..9 written, rows 4..5 come back as NaN (not arena bytes)
+    rc, out, msg = _worklist(ctx, g, [S(0, 4, _native.MODE_X, 200, 0, 0), S(4, 8, _native.MODE_X, 200, 200, 6 * 32)], 10)
+    assert rc == _native.OK, msg
+    assert np.isnan(out[4:6]).all() and np.isfinite(out[:4]).any() and np.isfinite(out[6:]).any()
+    assert not (out == -7.0).any()
+
+
+def test_calls_leave_the_current_device_alone():
+    """every entry point used to hipSetDevice(ctx->device) and leave it set.  On a one-GPU box the
+    observable part is that torch's current device and stream still work after calls on another thread's
+    context; with two GPUs the current device itself is checked."""
+    import torch
+    from pyrayhf_amd import _native, library
+    g = load_golden("g1_basic.npz")
+    n = _native.device_count()
+    before = torch.cuda.current_device()
+    for dev in range(min(n, 2)):
+        library.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 50, device=dev)
+        assert torch.cuda.current_device() == before
+    if n >= 2:
+        torch.cuda.set_device(1)
+        library.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 50, device=0)
+        t = torch.ones(4, device="cuda")                       # lands on the device the caller selected
+        assert torch.cuda.current_device() == 1 and t.device.index == 1
+        torch.cuda.set_device(before)
+    # raw HIP view of the same fact
+    hip = ctypes.CDLL("libamdhip64.so")
+    cur = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == torch.cuda.current_device()
+
+
+def test_host_call_after_a_torch_call_on_a_dead_side_stream():
+    """The torch path borrows torch's current stream; a later NumPy-path call must run on the context's own
+    stream again, even when the borrowed stream no longer exists."""
+    import gc
+    import torch
+    from pyrayhf_amd import library
+    g = load_golden("g5_chapman64.npz")
+    dev = torch.device("cuda:0")
+    t = [torch.as_tensor(g[k], device=dev) for k in ("freq", "den", "bmag", "bpsi", "alt")]
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        a = library.vertical_forward_operator(*t, "X", 2000)
+    side.synchronize()
+    want = a.cpu().numpy()
+    del side
+    gc.collect()
+    torch.cuda.empty_cache()
+    host = library.vertical_forward_operator(*(g[k] for k in ("freq", "den", "bmag", "bpsi", "alt")), "X", 2000)
+    assert np.array_equal(host, want, equal_nan=True)
+
+
+def test_tracer_reports_a_bad_device_resident_profile_index():
+    import torch
+    from pyrayhf_amd import _native
+    g = load_golden("g8_snell.npz")
+    prof = {k: torch.as_tensor(np.ascontiguousarray(g[f"gauss_{k}"]).reshape(1, -1), device="cuda") for k in ("den", "bmag", "bpsi")}
+    alt = torch.as_tensor(g["gauss_alt"], device="cuda")
+    n_alt = alt.numel()
+    f = torch.full((3,), 5e6, dtype=torch.float64, device="cuda")
+    e = torch.full((3,), 45.0, dtype=torch.float64, device="cuda")
+    out = torch.zeros((3, 8), dtype=torch.float64, device="cuda")
+    ctx = _native.host_context(0)
+    for idx, want_rc in (([0, 0, 0], _native.OK), ([0, 7, 0], _native.EINVAL), ([0, 0, -1], _native.EINVAL)):
+        pi = torch.tensor(idx, dtype=torch.int64, device="cuda")
+        rc = ctx.snell_cartesian(f.data_ptr(), e.data_ptr(), pi.data_ptr(), 3, prof["den"].data_ptr(), prof["bmag"].data_ptr(),
+                                 prof["bpsi"].data_ptr(), alt.data_ptr(), 1, n_alt, 0, _native.MODE_O, out.data_ptr(), 0, 0, 0,
+                                 _native.FLAG_DEVICE_PTRS)
+        assert rc == want_rc, (idx, rc, _native.last_error())
+        o = out.cpu().numpy()
+        assert np.isfinite(o[0, 0])                                   # the valid ray is traced either way
+        if want_rc != _native.OK:
+            bad = [i for i, v in enumerate(idx) if v != 0]
+            assert np.isnan(o[bad, 0]).all() and "profile_index" in _native.last_error()
