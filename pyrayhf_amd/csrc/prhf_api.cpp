@@ -40,8 +40,8 @@ int fail(int code, const char* fmt, ...) {
 
 long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
 constexpr size_t kPackBytes = 1u << 20;
-int kLeanMinPoints = 129;                  // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
-double kWellConditioned = 1e-4;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
+int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
+double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
@@ -364,7 +364,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         const bool stable = (flags & PRHF_FLAG_GRID_STABLE) != 0;
         if (!(stable && c->pairs.p && c->pairs_src == a.mult && c->pairs_len == mult_len)) {
             c->pairs_src = nullptr;
-            if ((rc = ensure(c, c->pairs, (size_t)mult_len * 16)) != PRHF_OK) return rc;
+            if ((rc = ensure(c, c->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
             HIP_TRY(prhf::launch_grid_pairs(a.mult, mult_len, static_cast<double*>(c->pairs.p), c->stream));
             if (stable) {
                 c->pairs_src = a.mult;
@@ -451,7 +451,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     }
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
     if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
-    if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(129, std::atoi(lm));
+    if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(2, std::atoi(lm));
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;

@@ -20,6 +20,7 @@
 #define PRHF_MAX_SEGMENTS 8
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 96          // one staged bottomside level
+#define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
 #ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
 #endif
@@ -79,7 +80,7 @@ inline size_t lds_bytes_for(long long n_alt) {
 
 hipError_t configure_kernels(size_t max_lds_bytes);
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
-// pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]
+// pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]; `pairs` holds n + PRHF_PAIR_PAD entries
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 // a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull

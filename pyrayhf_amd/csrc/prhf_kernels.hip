@@ -165,9 +165,7 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 // below, mu^2 < 0 makes w (and with it q) NaN.  Hence: keep the point iff q > kQCliff.
 constexpr double kQCliff = -3.3306690738754696e-16;   // -1.5 * 2^-52
 
-// POSD: the caller knows D > 0 (true wherever X + Y < 1 in X mode and X < 1 in O mode, i.e. on the
-// integration path below the reflection height) and skips the sign transfer.
-template <int MODE, bool POSD = false>
+template <int MODE>
 __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double* mu_out,
                                                 double* mup_out, double* q_out) {
 #pragma clang fp contract(fast)
@@ -186,15 +184,13 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
     const double Nw = N * w;
     const double mu = __builtin_fabs(Nw);
-    // q = X(1-X)/D = 1 - mu^2.  The generic callers test q against the mu > 1 cliff at the 1e-16 level and
-    // need its sign exact: q = X(1-X) * (N w^2).  The main loop (POSD) has no such test and takes
-    // 1 - (N w)^2: two instructions fewer, absolute error ~1e-15 (q only enters through q * J, J = O(Y)).
-    const double q = POSD ? 1.0 - Nw * Nw : XXm1 * (Nw * w);
+    // q = X(1-X)/D = 1 - mu^2.  The callers test q against the mu > 1 cliff at the 1e-16 level and need its
+    // sign exact: q = X(1-X) * (N w^2).  (The main loop, group_index_lean, has no such test.)
+    const double q = XXm1 * (Nw * w);
     const double Sp1 = (t * rbeta) * ((0.5 * sgn) * X + (0.5 * sgn)) + 1.0;     // 1 + s t (1 + X) / (2 beta)
     const double U = q * Sp1 + (D - X);
-    const double A = POSD ? w : __builtin_copysign(w, D);
     *mu_out = mu;
-    *mup_out = A * U;
+    *mup_out = __builtin_copysign(w, D) * U;
     *q_out = q;
 }
 
@@ -580,26 +576,63 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
     return mup;
 }
 
-// One grid point per lane on the lean path of the fast tier (uniform altitude grid, every segment
-// on the sin^2 cubic, span >= 0, not the last grid point).  g = (m_i, m_i+1 - m_i) from the pair
-// table; returns acc + mu' * (m_i+1 - m_i), or acc where the reference's term is NaN (:233, :238,
-// :288) - the caller multiplies the sum by span once (:415).
-// CHECK: also report (in `viol`, a lane mask) the points whose X is not below x_max - the caller of the
-// faithful tier's default mode only accepts wave-iterations where the reduced arithmetic is safe.
+// The group index of the main loop: mu' from the interpolated density, field strength and sin^2(psi), in the
+// reduced form of index_fast_core specialised for the integration path below the reflection height, where
+// D > 0 (X < 1 in O mode, X + Y < 1 in X mode, at every level and therefore between the levels: the three
+// interpolants are linear) - no sign transfer, no validity compare - and written around a = 1 - X:
+//   G = s beta - h,  D = a + G,  N = D - X a = G + a^2,  D - X = D - cX den,  (1 + X)/2 = k
+// 32 instructions from (den, b, S2): 15 FMA, 14 MUL, 1 ADD, 2 v_rsq_f64 (the version through X needed 34).
+// khcX = 0.5 s cX (s = +1 O, -1 X) rides in a scalar register like cX and cY2.
+template <int MODE>
+__device__ __forceinline__ double group_index_lean(double den, double b, double S2, double cX, double khcX,
+                                                   double cY2, double* a_out) {
+#pragma clang fp contract(fast)
+    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
+    const double a = __builtin_fma(-cX, den, 1.0);             // 1 - X
+    const double B2 = b * b;
+    const double YT2 = (cY2 * B2) * S2;
+    const double YL2 = __builtin_fma(cY2, B2, -YT2);           // Y^2 cos^2 psi
+    const double t = a * YL2;
+    const double h = 0.5 * YT2;
+    const double alpha = __builtin_fma(h, h, t * a);
+    const double rbeta = rsqrt_tier<MODE>(alpha);
+    const double G = __builtin_fma(sgn * alpha, rbeta, -h);    // s beta - h
+    const double D = a + G;
+    const double N = __builtin_fma(a, a, G);                   // D - X (1 - X)
+    const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
+    const double DmX = __builtin_fma(-cX, den, D);
+    const double k = __builtin_fma(khcX, den, 0.5 * sgn);      // s (1 + X) / 2
+    const double Sp1 = __builtin_fma(k, t * rbeta, 1.0);       // 1 + s t (1 + X) / (2 beta)
+    const double Nw = N * w;
+    const double q = __builtin_fma(-Nw, Nw, 1.0);              // X (1 - X) / D = 1 - mu^2
+    const double U = __builtin_fma(Sp1, q, DmX);
+    *a_out = a;
+    return w * U;
+}
+
+// One grid point per lane on the lean path (uniform altitude grid or hint table, every segment on the
+// sin^2 polynomial, span > 0).  g = (m_i, weight_i) - the weight is m_i+1 - m_i from the pair table, or what
+// the caller put there (0 for a masked lane, 1e-6 / span for the last grid point, :415-416); returns
+// acc + mu' * weight - the caller multiplies the sum by span once (:415).
+// A NaN term (mu^2 < 0 by rounding, :233) makes the sum NaN: the caller notices and re-runs the pair through
+// the generic loop, whose nansum skips such terms one by one (:288).  Validity needs no compare here: with
+// D > 0, q = X(1-X)/D >= 0, so the mu > 1 cliff (:238) cannot trigger.
+// CHECK: also report (in `viol`, a lane mask) the points whose 1 - X is not above `wc` - the default O-mode
+// arithmetic only accepts wave-iterations where the reduced algebra is safe.
 // QUAD: every segment of the profile carries the economised quadratic (u3 = 0, not read).
 // HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
 template <int MODE, bool CHECK, bool QUAD, bool HINT>
-__device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int K, double2 g, double span,
-                                            double a0, double kj, double cX, double cY2, double acc,
-                                            double x_max, unsigned long long& viol, unsigned nodes_v,
-                                            unsigned hint_v) {
+__device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX, double khcX,
+                                            double cY2, double acc, double wc, unsigned long long& viol,
+                                            unsigned nodes_v, unsigned hint_v) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
     // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here.  (A float
     // "magic number" add cannot replace the conversion: it rounds to nearest, and the interpolants are
-    // anchored at the level BELOW the point.)
+    // anchored at the level BELOW the point; the bias of -1/2 that would fix that is not representable
+    // next to 2^52.)
     int j = (int)(m0 * kj);
     typedef __attribute__((address_space(3))) const char* LdsBytes;
     typedef __attribute__((address_space(3))) const double* LdsDouble;
@@ -640,58 +673,52 @@ __device__ __forceinline__ double lean_step(const Node* __restrict__ nodes, int 
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
     const double S2 = QUAD ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y));
-    double mu, mup, q;
-    const double X = den * cX;
-    if (CHECK) viol |= __ballot(!(X < x_max));
-    index_fast_core<MODE, true>(X, (b * b) * cY2, S2, &mu, &mup, &q);
-    // Validity (:233, :238) on this path, where 0 <= X and X (+ Y) < 1 hold at every level below the
-    // reflection height and therefore between the levels (all three interpolants are linear):
-    //   D > 0:  O mode D = (1-X) - h + beta >= 1-X;  X mode D > 0 <=> (1-X)(1 - YL^2) > YT^2, which
-    //           1-X > Y, Y < 1 imply;
-    //   hence q = X(1-X)/D >= 0 and the mu > 1 cliff (:238) cannot trigger;
-    //   mu^2 < 0 (:233) only by rounding at the last grid points: there w = rsqrt(N D) and mu' are NaN.
-    // The group index c/v_g of a propagating mode is positive, so max(mu', 0) - which returns 0 for a
-    // NaN - is the nansum's selection in one instruction.
-    return __builtin_fma(fmax(mup, 0.0), g.y, acc);
+    double a;
+    const double mup = group_index_lean<MODE>(den, b, S2, cX, khcX, cY2, &a);
+    if (CHECK) viol |= __ballot(!(a > wc));
+    return __builtin_fma(mup, g.y, acc);
 }
 
-// The fast tier's main loop over the whole wave-iterations of [first, full_end) - all of them that end
-// at or before full_end - 64: returns span * sum of mu' * (m_i+1 - m_i) (per lane).
+// The main loop over grid points [first, end) of one pair: returns span * sum of mu' * weight (per lane).
+// Whole wave-iterations run two per trip with scalar loop control and no lane masks; a last partial one
+// carries its idle lanes along as copies of grid point 0 with weight 0.  `last_special` >= 0 (then
+// end == last_special + 1): that grid point is the last of the grid, its thickness is 1e-6 km, not a grid
+// step (:415-416) - it always sits in the partial iteration.
 // Deliberately NOT inlined: inside the fused kernel ~100 wave-uniform values are live around this loop,
 // and whenever the register allocator ran out of SGPRs it parked the buffer descriptor in VGPR lanes and
 // paid 8 v_readlane per trip (seen three times while the surrounding code changed).  As a function the
 // loop keeps its dozen scalars in SGPRs whatever the caller looks like; the call costs ~100 cycles per pair.
 struct LeanResult {
-    double acc;     // span * sum of mu' * (m_i+1 - m_i), per lane
+    double acc;     // span * sum of mu' * weight, per lane
     int first;      // first grid point not consumed
 };
 
-// CHECK (faithful tier, default mode): stop in front of the first trip that holds a point with
+// CHECK (default O-mode arithmetic): stop in front of the first trip that holds a point with
 // 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
 template <int MODE, bool CHECK, bool QUAD, bool HINT>
-__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds, int K,
-                                                          const double2* __restrict__ pairs, int first,
-                                                          int full_end, double span, double a0, double kj,
+__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds,
+                                                          const double2* __restrict__ pairs, int first, int end,
+                                                          int last_special, double span, double a0, double kj,
                                                           double cX, double cY2, double well_conditioned) {
 #pragma clang fp contract(fast)
     // arguments arrive in VGPRs: back to SGPRs.  The node table travels as its 32-bit LDS address (a
     // generic pointer would turn every node read into a flat load).
-    typedef __attribute__((address_space(3))) const Node* LdsNodes;
-    const Node* nodes = (const Node*)(LdsNodes)(uintptr_t)(unsigned)uniform((int)nodes_lds);
-    K = uniform(K); first = uniform(first); full_end = uniform(full_end);
+    first = uniform(first); end = uniform(end); last_special = uniform(last_special);
     span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX); cY2 = uniform(cY2);
-    const double x_max = CHECK ? uniform(1.0 - well_conditioned) : 0.0;
+    const double khcX = uniform((MODE == PRHF_KMODE_O ? 0.5 : -0.5) * cX);
+    const double wc = CHECK ? uniform(well_conditioned) : 0.0;
     pairs = reinterpret_cast<const double2*>(
         ((unsigned long long)(unsigned)uniform((int)((unsigned long long)pairs >> 32)) << 32) |
         (unsigned)uniform((int)(unsigned long long)pairs));
     const int lane = threadIdx.x & 63;
     double a0v = a0;                                   // VGPR copies: v_fma / v_mad take one SGPR operand
-    unsigned nodes_v = (unsigned)(uintptr_t)(LdsNodes)nodes;
+    unsigned nodes_v = (unsigned)uniform((int)nodes_lds);
     unsigned hint_v = (unsigned)uniform((int)hint_lds);
     asm volatile("" : "+v"(a0v), "+v"(nodes_v), "+v"(hint_v));
     // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
-    // SGPR, so the loop spends no vector instruction on addresses (indices are in bounds by
-    // construction: the last load of a trip ends before full_end <= n_points - 1).
+    // SGPR, so the loop spends no vector instruction on addresses.  A prefetch may reach up to 127 entries
+    // past `end`: the table is padded by PRHF_PAIR_PAD entries (launch_grid_pairs), and what is read there
+    // is never used.
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double2*>(pairs), 0, 0x7fffffff, 0x00020000);
@@ -702,30 +729,46 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         __builtin_memcpy(&g, &v, sizeof g);
         return g;
     };
-    double accm = 0.0;                                 // sum of mu' * (m_i+1 - m_i)
+    // whole iterations: all 64 points below `end` and none of them the special last point
+    const int whole_end = first + (((last_special >= 0 ? last_special : end) - first) & ~63);
+    double accm = 0.0;                                 // sum of mu' * weight
     unsigned long long viol = 0;
     double2 g0 = grid_at(first);
     // two wave-iterations per trip so that the prefetch registers swap roles without moves
-    for (; first + 192 <= full_end; first += 128) {
-        const double2 g1 = grid_at(first + 64);        // next iteration, in bounds
+    for (; first + 128 <= whole_end; first += 128) {
+        const double2 g1 = grid_at(first + 64);
         if (!CHECK) {
-            accm = lean_step<MODE, false, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, QUAD, HINT>(nodes, K, g1, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, QUAD, HINT>(g1, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
         } else {
-            const double a1 = lean_step<MODE, true, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
+            const double a1 = lean_step<MODE, true, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, QUAD, HINT>(nodes, K, g1, span, a0v, kj, cX, cY2, a1, x_max, viol, nodes_v, hint_v);
+            const double a2 = lean_step<MODE, true, QUAD, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol, nodes_v, hint_v);
             if (viol) break;                           // neither half of this trip counts
             accm = a2;
             g0 = g2;
         }
     }
-    if (!(CHECK && viol) && first + 128 <= full_end) { // odd wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(nodes, K, g0, span, a0v, kj, cX, cY2, accm, x_max, viol, nodes_v, hint_v);
+    if (!(CHECK && viol) && first + 64 <= whole_end) { // odd whole wave-iteration left over
+        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
+            g0 = grid_at(first);
+        }
+    }
+    if (!(CHECK && viol) && first < end) {             // partial wave-iteration: at most 64 points left
+        const int idx = first + lane;
+        const bool is_last = idx == last_special;
+        const bool live = idx < end;
+        double2 g = g0;
+        if (is_last) g.y = kBackoff / span;            // :415-416: the last thickness is 1e-6 km
+        if (!live) g = make_double2(0.0, 0.0);         // an idle lane re-evaluates grid point 0 with weight 0
+        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(g, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+        if (!(CHECK && viol)) {
+            accm = a1;
+            first = end;
         }
     }
     LeanResult r;
@@ -757,22 +800,24 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     int first = i0;                                // first grid point of the next wave-iteration
     if (!UNMAG && poly_angle && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
         // Lean main loop of the common case (slowly turning field; uniform altitude grid, or any grid
-        // through the hint table): whole wave-iterations that neither touch the last grid point nor need
-        // lane masks, so there is no index clamping, no exec masking and the loop control is scalar.
-        // The wave-iterations that remain go through the generic loop below: at most three in the
-        // fast tier; in the faithful tier's default mode also everything from the first trip on that
-        // holds a point with 1 - X <= well_conditioned.
+        // through the hint table).  Fast tier: it takes every grid point of the range, the last one of the
+        // grid (thickness 1e-6 km) included, so nothing is left for the generic loop below.  Default O-mode
+        // arithmetic: it takes the points up to the last 64 of the range - those, and everything from the
+        // first trip on that holds a point with 1 - X <= well_conditioned, go through the generic loop in the
+        // reference's operation order.
 #pragma clang fp contract(fast)
         first = uniform(first);
-        const int full_end = uniform(i1 < last ? i1 : last);   // i < full_end  =>  i < i1 and i + 1 <= last
+        const bool to_grid_end = i1 == n_points;
+        const int lean_end = uniform(TIER == 1 ? i1 : (i1 - 64 > first ? i1 - 64 : first));
+        const int last_special = (TIER == 1 && to_grid_end) ? last : -1;
         // index scale: (z - a0) / step = m * kj on a uniform grid, hint buckets per unit of m otherwise
         const bool by_hint = !info.uniform;
         // (the bucket scale is biased low by 1e-11: rounding must never select the bucket ABOVE the point,
         // whose hinted level could lie above it too - one bucket too low only lengthens the walk up)
         const double kj = uniform(by_hint ? span * info.inv_w * (1.0 - 1e-11) : span * info.inv_step);
-        // span < 0: left clamp, generic loop; the bound on kj keeps the closed-form index inside its table
+        // span <= 0: left clamp, generic loop; the bound on kj keeps the closed-form index inside its table
         const bool in_table = by_hint ? (kj < (double)kHintBuckets && info.inv_w > 0.0) : (kj <= (double)(K - 1));
-        if (first + 128 <= full_end && span >= 0.0 && in_table) {
+        if (lean_end > first && span > 0.0 && in_table) {
             // the loop is a function of its own (not inlined): it gets a fresh scalar-register budget,
             // see lean_loop
             typedef __attribute__((address_space(3))) const Node* LdsNodes;
@@ -781,13 +826,20 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
             const bool quad = info.poly_angle == 2;
             LeanResult r;
-#define PRHF_LEAN(Q, H) lean_loop<MODE, TIER == 0, Q, H>(nodes_lds, hint_lds, K, pairs, first, full_end, span, a0, \
-                                                           kj, cX, cY2, well_conditioned)
+#define PRHF_LEAN(Q, H) lean_loop<MODE, TIER == 0, Q, H>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
+                                                           span, a0, kj, cX, cY2, well_conditioned)
             if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
             else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
 #undef PRHF_LEAN
-            acc = r.acc;
-            first = uniform(r.first);
+            // a NaN term (mu^2 < 0 by rounding, :233) or an infinite one (mu^2 == 0) poisons the lane sum: then
+            // the whole range goes through the generic loop, whose nansum drops such terms one by one (:288)
+            if (uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
+                acc = 0.0;
+                first = uniform(i0);
+            } else {
+                acc = r.acc;
+                first = uniform(r.first);
+            }
         }
     }
     // Generic loop over [first, i1).  Its wave-iterations are aligned to the END of the range - a short first
@@ -1032,15 +1084,20 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
 // own whatever the caller passed (fmax/fmin also turn a NaN into 0).
 __global__ void grid_pairs_kernel(const double* __restrict__ mult, long long n, double2* __restrict__ pairs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n + PRHF_PAIR_PAD) return;
+    if (i >= n) {                                  // padding: the main loop's prefetch may read it, nothing uses it
+        pairs[i] = make_double2(0.0, 0.0);
+        return;
+    }
     const double m = mult[i];
     pairs[i] = make_double2(fmin(fmax(m, 0.0), 1.0), (i + 1 < n ? mult[i + 1] : m) - m);
 }
 
+// pairs must hold n + PRHF_PAIR_PAD entries
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(grid_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mult, n,
-                       reinterpret_cast<double2*>(pairs));
+    hipLaunchKernelGGL(grid_pairs_kernel, dim3((unsigned)((n + PRHF_PAIR_PAD + 255) / 256)), dim3(256), 0, stream, mult,
+                       n, reinterpret_cast<double2*>(pairs));
     return hipGetLastError();
 }
 

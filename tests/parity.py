@@ -86,6 +86,9 @@ def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WIT
     if noise is None:
         limit = np.full(want.shape, O_TOL)
     else:
+        noise = np.asarray(noise, dtype=np.float64)
+        if noise.ndim > want.ndim:                         # a (1, F) floor for one (F,) profile
+            noise = noise.reshape(want.shape)
         limit = np.maximum(O_TOL, factor * effective_noise(np.broadcast_to(noise, want.shape)))
     over = ok & (err > limit)
     assert not over.any(), (f"O-mode: {int(over.sum())} pairs beyond max(1e-6, {factor}*noise); worst "

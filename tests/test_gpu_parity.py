@@ -73,10 +73,12 @@ def test_chapman_batch_g5(lib):
     assert_o_mode(vo, g["O_200_vh"], combined_noise(g["O_200_noise"], load_golden("g12_rounding_noise.npz")["g5_O_200"]))
     vx = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 2000)
     assert_x_mode(vx, g["X_2000_vh"])
-    # batch == loop of single-profile calls (a lone profile is cut into more chunks, so the
-    # summation order differs: agreement to rounding, not bit for bit)
+    # batch == loop of single-profile calls.  Not bit for bit: a lone profile is cut into chunks (another
+    # summation order) and, with 174 pairs on a 2000-point grid, skips the pair table and runs the generic
+    # loop (exact segment search) where the batch runs the main loop (closed-form segment index): the two
+    # evaluations agree to ~1e-12, thirty times below the reference's own +-1 ulp response in X mode (3e-11)
     one = lib.vertical_forward_operator(g["freq"], g["den"][5], g["bmag"][5], g["bpsi"][5], g["alt"], "X", 2000)
-    assert_x_mode(one, vx[5], tol=1e-12)
+    assert_x_mode(one, vx[5], tol=1e-11)
 
 
 def test_config3_rows_o_mode_g10(lib):

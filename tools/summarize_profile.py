@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/profile.sh output directory into profiles/<tag>.md (+ hbm_traffic.json).
 
-    python tools/summarize_profile.py gpurun_out/prof_r01_v2 r01_v2 [workload-key]
+    python tools/summarize_profile.py gpurun_out/prof_r01_v2 r01_v2 [workload-key] [kernel-substring] [description]
 
 Kernel time comes from `rocprofv3 --kernel-trace --stats`; counters from separate `--pmc`
 passes.  HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB
@@ -24,10 +24,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     key = sys.argv[3] if len(sys.argv) > 3 else "X_20000_12500x256"
-    kernel = "vfo_kernel"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "vfo_kernel"
+    desc = sys.argv[5] if len(sys.argv) > 5 else ("bench.py default workload: 12 500 profiles x 256 freqs, X-mode, "
+                                                  "n_points = 20000, fast tier")
     lines = [f"# rocprofv3 summary `{tag}`", "",
-             f"Source: `tools/profile.sh {tag}` on one MI355X (bench.py default workload `{key}`: "
-             "12 500 profiles x 256 freqs, X-mode, n_points = 20000, fast tier).", ""]
+             f"Source: `tools/profile.sh {tag}` on one MI355X, workload `{key}` ({desc}); counters are those of the "
+             f"dispatches whose kernel name contains `{kernel}`.", ""]
 
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     avg_ns = None
@@ -56,7 +58,7 @@ def main():
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
     mean = {k: sum(v) / len(v) for k, v in counters.items()}
     if mean:
-        lines += ["## Counters (separate `--pmc` passes, mean per dispatch of the fused kernel)", "",
+        lines += ["## Counters (separate `--pmc` passes, mean per dispatch of the selected kernel)", "",
                   "| counter | value |", "|---|---|"]
         for k in sorted(mean):
             lines.append(f"| {k} | {mean[k]:.6g} |")
@@ -107,6 +109,18 @@ def main():
                            f"({100 * corrected / (avg_ns * 1e-9) / 8e12:.4f} % of 8 TB/s)")
         record.update(hbm_bytes_per_launch=corrected, fetch_kib=mean["FETCH_SIZE"], write_kib=mean["WRITE_SIZE"],
                       kernel_ms=avg_ns / 1e6 if avg_ns else None, source=f"profiles/{tag}.md")
+    log = os.path.join(src, "trace.log")
+    if os.path.exists(log) and avg_ns:
+        for ln in open(log):
+            if ln.startswith("{") and '"roofline"' in ln:
+                b = json.loads(ln)
+                nominal = b["roofline"]["achieved"] * b["kernel_ms"] * 1e-3          # TFLOP per launch (SURVEY 8d count)
+                derived.append(f"* nominal roofline (68 flop per reflecting grid point + 6 per level and pair = "
+                               f"{nominal:.4g} TFLOP per launch) over this trace's kernel average: "
+                               f"**{nominal / (avg_ns * 1e-9):.2f} TFLOP/s = {100 * nominal / (avg_ns * 1e-9) / 78.6:.1f} %** "
+                               f"of the 78.6 TFLOP/s FP64 vector peak; {b['value'] * b['ms_per_step'] / (avg_ns / 1e6):.4g} "
+                               f"integrals/s at that kernel time")
+                record["nominal_tflop_per_launch"] = nominal
     if derived:
         lines += ["## Derived", ""] + derived + [""]
 
