@@ -42,6 +42,8 @@ long long kTargetWaves = 4096;             // waves resident at two 8-wave workg
 constexpr size_t kPackBytes = 1u << 20;
 int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
 double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
+int kTailGroupMinPoints = 81;             // PRHF_TAIL_GROUP_MIN / _MAX: grids of this many points take four frequencies per item
+int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 of them are ill conditioned: nothing to share)
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
@@ -94,6 +96,7 @@ struct prhf_ctx {
     DevBuf partial;   // chunk sums
     DevBuf altmin;    // per-profile min(alt) for chunked slices
     DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
+    DevBuf ftab;      // per-frequency scalars of a long launch
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
     unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1] block queue of persistent launches
@@ -137,7 +140,10 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     }
     s.chunks = (int)chunks;
     s.chunk_len = (int)chunk_len;
-    const long long items = n_freq * chunks;
+    // short grids in the default O-mode arithmetic: four frequencies per item (run_items_tail16)
+    s.group = (s.tier == 0 && s.well_conditioned < 1.0 && s.lean && chunks == 1 && N >= kTailGroupMinPoints &&
+               N <= kTailGroupMaxPoints) ? 4 : 1;
+    const long long items = s.group == 4 ? (n_freq + 3) / 4 : n_freq * chunks;
     long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
                                                                  std::max<long long>(P, 1)));
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -233,7 +239,6 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         // reduced algebra elsewhere; PRHF_MATH_FAITHFUL keeps the reference's order everywhere
         s.well_conditioned = (c->math == PRHF_MATH_AUTO && s.tier == 0) ? kWellConditioned : HUGE_VAL;
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
-        plan_slice(s, n_freq, wg_slots);
         // the main loop needs the pair table: one more (small) kernel unless the caller's grid is cached - not
         // worth it for a handful of pairs on a short grid, where the launch itself is the cost
         const long long seg_pairs = (u.prof_end - u.prof_begin) * n_freq;
@@ -242,6 +247,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.lean = ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
                   table_is_cheap) ? 1 : 0;
         want_pairs = want_pairs || s.lean != 0;
+        plan_slice(s, n_freq, wg_slots);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
     // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup
@@ -372,6 +378,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             }
         }
         a.pairs = static_cast<const double*>(c->pairs.p);
+        // per-frequency scalars: long launches read them from a table instead of dividing once per pair
+        if ((rc = ensure(c, c->ftab, (size_t)n_freq * 64)) != PRHF_OK) return rc;
+        HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), c->stream));
+        a.ftab = static_cast<const double*>(c->ftab.p);
     }
 #ifdef PRHF_TRACE
     // diagnostics build (tools/wave_trace.py): per-wave wall-clock stamps of this launch, dumped to $PRHF_TRACE_FILE
@@ -452,6 +462,8 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
     if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
     if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(2, std::atoi(lm));
+    if (const char* g0 = std::getenv("PRHF_TAIL_GROUP_MIN")) kTailGroupMinPoints = std::max(81, std::atoi(g0));
+    if (const char* g1 = std::getenv("PRHF_TAIL_GROUP_MAX")) kTailGroupMaxPoints = std::atoi(g1);
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;
@@ -492,6 +504,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->partial.p) (void)hipFree(c->partial.p);
     if (c->altmin.p) (void)hipFree(c->altmin.p);
     if (c->pairs.p) (void)hipFree(c->pairs.p);
+    if (c->ftab.p) (void)hipFree(c->ftab.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_pack) (void)hipHostFree(c->h_pack);

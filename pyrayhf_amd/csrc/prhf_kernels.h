@@ -49,6 +49,8 @@ struct SegDev {
     double well_conditioned;
     int lean;                        // this slice uses the main loop (and KArgs::pairs); decided per slice so that a
                                      // slice gets the same arithmetic alone and inside a mixed launch
+    int group;                       // frequencies per work item: 1, or 4 on short grids in the default O-mode
+                                     // arithmetic (run_items_tail16: four 16-point tails share one wave-iteration)
 };
 
 struct KArgs {
@@ -59,6 +61,7 @@ struct KArgs {
     const double* alt;
     const double* mult;
     const double* pairs;             // (m_i, m_i+1 - m_i) interleaved, same indexing as mult; may be null
+    const double* ftab;              // (n_freq, 8) per-frequency scalars (freq_table_kernel); null: computed per pair
     double* out;
     double* partial;
     double* altmin;
@@ -82,6 +85,8 @@ hipError_t configure_kernels(size_t max_lds_bytes);
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
 // pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]; `pairs` holds n + PRHF_PAIR_PAD entries
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
+// tab[8 f ..] = f_hz, f2, cp^2/f2, (g_p/f)^2, 1/f2, 1/f_hz, 0, 0
+hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 // a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull
 // block indices from the queue, else grid_blocks must equal a.n_blocks

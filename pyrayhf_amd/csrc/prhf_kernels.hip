@@ -786,14 +786,11 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                                                   const unsigned short* __restrict__ hint,
                                                   const BlockInfo& info, const double* __restrict__ mult,
                                                   const double2* __restrict__ pairs, int n_points, int i0,
-                                                  int i1, double f_hz, double f2, double h_refl, int lane,
-                                                  double well_conditioned) {
+                                                  int i1, double f_hz, double f2, double cX, double cY2,
+                                                  double h_refl, int lane, double well_conditioned) {
     const int K = info.K;
     const double a0 = info.a0;
     const double span = uniform(h_refl - a0);      // :413 (critical_height - aalt[0])
-    const double cX = uniform((kPlasma * kPlasma) / f2);
-    const double cY = kGyro / f_hz;
-    const double cY2 = uniform(cY * cY);
     const bool poly_angle = info.poly_angle != 0;
     const int last = n_points - 1;
     double acc = 0.0;
@@ -895,6 +892,67 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     return wave_sum(acc);
 }
 
+// Per-frequency scalars of a pair.  Long launches read them from a table built once per launch
+// (freq_table_kernel: F x 8 doubles, one 64-byte row per frequency, fetched with the wave-uniform index);
+// short ones compute them in place.  f_hz, f2 are the reference's own values (:491, f**2); cX, cY2 only
+// feed the reduced algebra; inv_f2, inv_f only feed the sufficient "escapes for certain" test.
+struct PairFreq {
+    double f_hz, f2, cX, cY2, inv_f2, inv_f;
+};
+__device__ __forceinline__ PairFreq pair_freq(const KArgs& a, int f) {
+#pragma clang fp contract(off)
+    PairFreq p;
+    if (a.ftab) {
+        const double* row = a.ftab + 8 * (long long)f;
+        p.f_hz = uniform(row[0]); p.f2 = uniform(row[1]); p.cX = uniform(row[2]); p.cY2 = uniform(row[3]);
+        p.inv_f2 = uniform(row[4]); p.inv_f = uniform(row[5]);
+    } else {
+        p.f_hz = uniform(a.freq[f] * 1e6);                     // :491
+        p.f2 = uniform(p.f_hz * p.f_hz);                       // f**2
+        p.cX = uniform((kPlasma * kPlasma) / p.f2);
+        const double cY = kGyro / p.f_hz;
+        p.cY2 = uniform(cY * cY);
+        p.inv_f2 = uniform(1.0 / p.f2);
+        p.inv_f = uniform(1.0 / p.f_hz);
+    }
+    return p;
+}
+
+// S3-S6 of one pair: does the frequency reflect, and where.  First a sufficient test for "escapes": division
+// and addition are monotone, so the reference's X (O mode) or X + Y (X mode) at every level is <= the same
+// expression of the two per-profile maxima; when that bound - evaluated with reciprocals, so good to a few
+// ulp - stays 1e-9 below 1, the running maximum cannot reach 1 (:399) and the level scan is skipped (it is
+// most of the per-pair cost when n_points is small).  Otherwise the scan decides, exactly.
+// (K == 1 keeps the full path: np.interp's one-node quirk.)
+template <int MODE>
+__device__ __forceinline__ bool pair_reflects(const Node* nodes, const double* pf2, const double* gb,
+                                              const BlockInfo& info, const double* keep, const PairFreq& pf,
+                                              int lane, double* h_out) {
+    if (info.K > 1) {
+        double ub = keep[kKeepPf2Max] * pf.inv_f2;
+        if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] * pf.inv_f;
+        if (uniform((int)(ub < 1.0 - 1e-9))) return false;
+    }
+    double h = 0.0;
+    const bool r = uniform((int)reflection_height<MODE>(nodes, pf2, gb, info.K, pf.f_hz, pf.f2, lane, &h)) != 0;
+    *h_out = uniform(h);
+    return r;
+}
+
+// A one-level bottomside: np.interp with a single node returns that node even for the NaN abscissae of an
+// escaping frequency (numpy arr_interp, lenxp == 1), so the reference's sum keeps the last term
+// mu'(level 0) * 1e-6 (:415-416, :288).
+template <int MODE, int TIER>
+__device__ __forceinline__ double one_level_term(const Node* nodes, const BlockInfo& info, const PairFreq& pf,
+                                                 double well_conditioned) {
+    const bool poly = info.poly_angle != 0;
+    const double mup = info.unmag
+        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned)
+        : point_mup<MODE, TIER, false>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned);
+    const double term = mup * kBackoff;
+    return (term == term) ? term : 0.0;
+}
+
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
@@ -924,53 +982,28 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
         return uniform((u / W) * round_items + first_item + (u % W));
     };
     for (int t = next_item(); t < T; t = next_item()) {
-        const int f = t % F;
-        const int c = t / F;
+        int f = t, c = 0;
+        if (C > 1) {                               // (unchunked launches spare the integer division)
+            f = t % F;
+            c = t / F;
+        }
         double result = qnan();
         bool reflects = false;
         if (!info.bad) {
-            const double f_hz = uniform(a.freq[f] * 1e6);      // :491
-            const double f2 = uniform(f_hz * f_hz);            // f**2
+            const PairFreq pf = pair_freq(a, f);
             double h = 0.0;
-            // Escapes for certain?  Division and addition are monotone, so the reference's X (O mode) or
-            // X + Y (X mode) at every level is <= the same expression of the two maxima: below 1 there, the
-            // running maximum never reaches 1 (:399) and the level scan can be skipped - it is most of the
-            // per-pair cost when n_points is small.  (K == 1 keeps the full path: np.interp's one-node quirk.)
-            int scan = 1;
-            if (info.K > 1) {
-#pragma clang fp contract(off)
-                double ub = keep[kKeepPf2Max] / f2;
-                if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] / f_hz;
-                scan = uniform((int)!(ub < 1.0));
-            }
-            if (scan) {
-                reflects = uniform((int)reflection_height<MODE>(nodes, pf2, gb, info.K, f_hz, f2, lane, &h)) != 0;
-                h = uniform(h);
-            }
+            reflects = pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h);
             if (reflects) {
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
                 if (info.unmag)
                     result = integrate_chunk<MODE, TIER, true>(nodes, hint, info, mult, pairs, sg.n_points, i0, i1,
-                                                               f_hz, f2, h, lane, wc);
+                                                               pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
                 else
                     result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, sg.n_points, i0,
-                                                                i1, f_hz, f2, h, lane, wc);
+                                                                i1, pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
             } else if (info.K == 1) {
-                // A one-level bottomside: np.interp with a single node returns that node even
-                // for the NaN abscissae of an escaping frequency (numpy arr_interp, lenxp == 1),
-                // so the reference's sum keeps the last term mu'(level 0) * 1e-6 (:415-416, :288).
-                const double cX = (kPlasma * kPlasma) / f2, cY = kGyro / f_hz;
-                double term = 0.0;
-                if (c == C - 1) {
-                    const bool poly = info.poly_angle != 0;
-                    const double mup = info.unmag
-                        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly, sg.well_conditioned)
-                        : point_mup<MODE, TIER, false>(nodes[0], 0.0, f_hz, f2, cX, cY * cY, poly, sg.well_conditioned);
-                    term = mup * kBackoff;
-                    if (!(term == term)) term = 0.0;
-                }
-                result = term;
+                result = (c == C - 1) ? one_level_term<MODE, TIER>(nodes, info, pf, sg.well_conditioned) : 0.0;
                 reflects = true;
             }
         }
@@ -983,6 +1016,125 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 a.partial[sg.partial_off + (pair_base + f) * C + c] = reflects ? result : qnan();
             }
         }
+    }
+}
+
+// Short grids in the default O-mode arithmetic (BASELINE config 3: n_points = 200): an item is FOUR
+// consecutive frequencies.  What costs most there is not the 200 points but the one wave-iteration in the
+// reference's operation order (~500 vector instructions) that every reflecting pair needs for its
+// ill-conditioned last points - and those are few: with the threshold 1 - X <= 1e-5 they are the last 1 to 4
+// of 200 grid points (98 % of the pairs: the last 16 at most).  So each pair runs the main loop, with its
+// check, over everything but its last 16 points, and the four tails of 16 share ONE wave-iteration in the
+// reference's order: lane l evaluates point n - 16 + (l & 15) of pair l >> 4 with that pair's own
+// frequency and reflection height.  A pair whose check fails before its tail (an E-F cusp, a bottom that
+// starts above cutoff) goes through the general path by itself.  Values do not depend on which pairs
+// share an iteration: the tail is always evaluated in the reference's order, point by point.
+constexpr int kTail = 16;
+template <int MODE, int THREADS>
+__device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& sg, const Node* nodes,
+                                                 const double* pf2, const double* gb,
+                                                 const unsigned short* hint, const BlockInfo& info,
+                                                 long long prof_local, int block_in_prof, int blocks_per_prof,
+                                                 int* item_next, const double* red) {
+    constexpr int W = THREADS / 64;
+    constexpr int TIER = 0;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane >> 4;                     // which of the item's four pairs this lane's tail point belongs to
+    const double* keep = kept_scalars<THREADS>(red);
+    const double wc = uniform(sg.well_conditioned);
+    const int F = uniform((int)a.n_freq);
+    const int T = (F + 3) >> 2;
+    const int n = uniform(sg.n_points);
+    const double* mult = a.mult + sg.mult_off;
+    const double2* pairs = reinterpret_cast<const double2*>(a.pairs) + sg.mult_off;
+    const long long pair_base = prof_local * F;
+    const int first_item = block_in_prof * W, round_items = blocks_per_prof * W;
+    auto next_item = [&]() {
+        const int u = uniform(atomicAdd(item_next, 1)) >> 6;
+        return uniform((u / W) * round_items + first_item + (u % W));
+    };
+    const double a0 = info.a0;
+    const bool by_hint = !info.uniform;
+    typedef __attribute__((address_space(3))) const Node* LdsNodes;
+    typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
+    const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
+    const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
+    const bool quad = info.poly_angle == 2;
+    const double alt_min = keep[kKeepAltMin];
+    const int ti = n - kTail + (lane & 15);        // this lane's tail point
+    for (int t = next_item(); t < T; t = next_item()) {
+        const int f0 = t << 2;
+        // per-lane parameters of the pair whose tail point this lane evaluates
+        double my_fhz = 1.0, my_f2 = 1.0, my_h = 0.0, my_sum = 0.0;
+        unsigned tail_mask = 0;                    // bit q: pair q takes part in the shared tail iteration
+        double my_done = qnan();                   // result of this lane's pair if it does not (NaN: escapes)
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const int f = f0 + q;
+            if (f >= F || info.bad) continue;
+            const PairFreq pf = pair_freq(a, f);
+            double h = 0.0;
+            if (!pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h)) continue;   // (K > 1 on this path)
+            const double span = uniform(h - a0);
+            const double kj = uniform(by_hint ? span * info.inv_w * (1.0 - 1e-11) : span * info.inv_step);
+            const bool in_table = by_hint ? (kj < (double)kHintBuckets && info.inv_w > 0.0)
+                                          : (kj <= (double)(info.K - 1));
+            bool shared = false;
+            if (span > 0.0 && in_table) {
+                LeanResult r;
+#define PRHF_LEAN(Q, H) lean_loop<MODE, true, Q, H>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
+                                                      pf.cX, pf.cY2, wc)
+                if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
+                else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
+#undef PRHF_LEAN
+                const double s = wave_sum(r.acc);
+                if (uniform(r.first) == n - kTail && uniform((int)(__builtin_fabs(s) <= 1.7976931348623157e308))) {
+                    shared = true;
+                    tail_mask |= 1u << q;
+                    if (sub == q) { my_fhz = pf.f_hz; my_f2 = pf.f2; my_h = h; my_sum = s; }
+                }
+            }
+            if (!shared) {                         // the general path, this pair by itself
+                const double total = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, n, 0, n,
+                                                                        pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
+                if (sub == q) my_done = (total != 0.0) ? total + alt_min : qnan();            // :290-292
+            }
+        }
+        double shared_vh = qnan();
+        if (tail_mask) {
+            // one wave-iteration in the reference's operation order for up to four tails of 16 points
+#pragma clang fp contract(off)
+            const bool live = (tail_mask >> sub) & 1u;
+            const double tm0 = mult[ti];                                         // (not kept across the loop calls above)
+            const double tm1 = mult[ti + 1 < n ? ti + 1 : ti];
+            const double span = my_h - a0;                                       // :413
+            const double z = tm0 * span + a0;
+            const double dh = (ti < n - 1) ? (tm1 * span + a0) - z : kBackoff;   // :415-416
+            int j = guess_segment(hint, info, z);
+            while (j > 0 && z < nodes[j].alt) --j;                               // np.interp: alt[j] <= z < alt[j+1]
+            while (j + 1 < info.K && z >= nodes[j + 1].alt) ++j;
+            const Node nd = nodes[j];
+            double dz = z - nd.alt;
+            if (dz < 0.0) dz = 0.0;
+            const double den = nd.sden * dz + nd.den;                            // numpy arr_interp
+            const double fn = sqrt(den) * kPlasma;                               // :96
+            const double X = (fn * fn) / my_f2;                                  // :136
+            const double b = nd.sb * dz + nd.b;
+            const double psi = nd.spsi * dz + nd.psi;
+            const double Y = (kGyro * b) / my_fhz;                               // :157
+            double mu, mup;
+            index_faithful<MODE>(X, Y, psi, &mu, &mup);
+            double term = mup * dh;                                              // :288
+            if (!(live && term == term)) term = 0.0;                             // nansum
+            // sum over the 16 lanes of each pair
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) term = term + __shfl_xor(term, off);
+            const double total = my_sum + term;
+            shared_vh = (total != 0.0) ? total + alt_min : qnan();               // :290-292
+        }
+        // lanes 0, 16, 32, 48 store their pair's result
+        if ((lane & 15) == 0 && f0 + sub < F)
+            a.out[sg.out_off + pair_base + f0 + sub] = ((tail_mask >> sub) & 1u) ? shared_vh : my_done;
     }
 }
 
@@ -1006,7 +1158,15 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         if (info.bad) atomicOr(a.status, (unsigned)info.bad);
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
     }
-    if (sg.mode == PRHF_KMODE_O)
+    if (TIER == 0 && sg.group == 4 && !info.bad && !info.unmag && info.poly_angle != 0 && info.K > 1) {
+        // short grids, default O-mode arithmetic: four frequencies per item (run_items_tail16)
+        if (sg.mode == PRHF_KMODE_O)
+            run_items_tail16<PRHF_KMODE_O, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+                                                    blocks_per_prof, item_next, red);
+        else
+            run_items_tail16<PRHF_KMODE_X, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+                                                    blocks_per_prof, item_next, red);
+    } else if (sg.mode == PRHF_KMODE_O)
         run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     else
@@ -1098,6 +1258,26 @@ hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hip
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(grid_pairs_kernel, dim3((unsigned)((n + PRHF_PAIR_PAD + 255) / 256)), dim3(256), 0, stream, mult,
                        n, reinterpret_cast<double2*>(pairs));
+    return hipGetLastError();
+}
+
+// Per-frequency scalars of a launch (PairFreq): row f = {f_hz, f2, cX, cY2, 1/f2, 1/f_hz, 0, 0}.
+__global__ void freq_table_kernel(const double* __restrict__ freq_mhz, long long n_freq, double* __restrict__ tab) {
+#pragma clang fp contract(off)
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_freq) return;
+    const double f_hz = freq_mhz[f] * 1e6;                     // :491
+    const double f2 = f_hz * f_hz;                             // f**2
+    const double cY = kGyro / f_hz;
+    double* row = tab + 8 * f;
+    row[0] = f_hz; row[1] = f2; row[2] = (kPlasma * kPlasma) / f2; row[3] = cY * cY;
+    row[4] = 1.0 / f2; row[5] = 1.0 / f_hz; row[6] = 0.0; row[7] = 0.0;
+}
+
+hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream) {
+    if (n_freq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(freq_table_kernel, dim3((unsigned)((n_freq + 255) / 256)), dim3(256), 0, stream, freq_mhz, n_freq,
+                       tab);
     return hipGetLastError();
 }
 
