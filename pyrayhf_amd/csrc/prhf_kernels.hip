@@ -833,6 +833,9 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             if (uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
                 acc = 0.0;
                 first = uniform(i0);
+#ifdef PRHF_MARK_FALLBACK
+                acc = 1e6;                          // diagnostics build (tools/count_fallbacks.py): such pairs show up 1e6 km too high
+#endif
             } else {
                 acc = r.acc;
                 first = uniform(r.first);

@@ -1,5 +1,6 @@
-"""Cost split of the fused kernel on the config-4 shard: staging only (one escaping frequency),
-staging + 256 reflection searches (all frequencies escape), and the full sweep."""
+"""Cost split of the fused kernel on the config-4 shard (12 500 profiles x 256 freqs, X mode): staging only,
+escaping pairs, and the full sweep at several grid sizes - the slope over n_points is the cost per grid
+point, the intercept the fixed cost per pair (scan, set-up, reduction)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -15,10 +16,11 @@ def run(name, freq, mode="X", n_points=20000, math=None):
         library.vertical_forward_operator(f, *t, mode, n_points, math=math)
         ms.append(ctx.last_kernel_ms())
     print(json.dumps({"case": name, "kernel_ms": min(ms[1:])}), flush=True)
+    return min(ms[1:])
+f4 = synth.sounder_frequencies(4)
 run("stage only: 1 escaping frequency", [30.0])
-run("stage + 256 escaping frequencies", np.full(256, 30.0))
-run("stage + 256 escaping, faithful tier staging", np.full(256, 30.0), math=0)
-run("stage + 64 escaping frequencies", np.full(64, 30.0))
-run("full config-4 sweep", synth.sounder_frequencies(4))
-run("full sweep, n_points 2000", synth.sounder_frequencies(4), n_points=2000)
-run("full sweep, n_points 200", synth.sounder_frequencies(4), n_points=200)
+run("stage + 256 certainly escaping frequencies", np.full(256, 30.0))
+times = {n: run(f"full sweep, n_points {n}", f4, n_points=n) for n in (320, 1280, 5120, 10000, 20000, 40000)}
+slope = (times[40000] - times[10000]) / 30000
+print(json.dumps({"ms_per_grid_point_of_all_pairs": slope, "intercept_ms": times[20000] - 20000 * slope,
+                  "note": "time(n) ~ intercept + slope * n over n = 10000..40000"}))
