@@ -16,7 +16,8 @@
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
 #endif
-#define PRHF_HINT_BUCKETS 2048      // uint16 segment hints, 4 KiB of LDS
+#define PRHF_HINT_BUCKETS 1024      // uint16 segment hints, 2 KiB of LDS (non-uniform altitude grids)
+#define PRHF_MAX_CAND 1024          // uint16 list of the frequencies that may reflect, 2 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 96          // one staged bottomside level
@@ -75,9 +76,9 @@ struct KArgs {
 };
 
 // n_alt + 1 nodes (the last one may be the +inf sentinel), f_N^2 and g_p*B per level,
-// segment hints, block-reduction scratch
+// segment hints, candidate frequencies, block-reduction scratch
 inline size_t lds_bytes_for(long long n_alt) {
-    return (size_t)(n_alt + 1) * PRHF_NODE_BYTES + (size_t)n_alt * 16 + PRHF_HINT_BUCKETS * 2 +
+    return (size_t)(n_alt + 1) * PRHF_NODE_BYTES + (size_t)n_alt * 16 + PRHF_HINT_BUCKETS * 2 + PRHF_MAX_CAND * 2 +
            PRHF_RED_DOUBLES * 8;
 }
 

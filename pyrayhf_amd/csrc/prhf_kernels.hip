@@ -218,6 +218,7 @@ __device__ __forceinline__ void index_unmagnetised(double X, double* mu_out, dou
 // np.interp(1.0, running_max, alt) semantics (library.py:388-407): j = last level whose
 // running maximum is <= 1; exact hit returns alt[j]; otherwise linear between j and j+1.
 // Always IEEE arithmetic: the comparisons with 1.0 decide NaN masks.
+// pf2: f_N^2 per level for X mode; its RUNNING MAXIMUM over the levels for O mode (prefix_max_in_place).
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes,
@@ -232,24 +233,26 @@ __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes
         // O mode compares one rounded quotient with 1, which needs no division: fl(a / b) > 1 <=> a / b >
         // 1 + 2^-53 (round to nearest even) <=> a - b > b 2^-53, where a - b is exact for b <= a <= 2b
         // (Sterbenz) and beyond 2b the test is true either way.  The running maximum of the quotients is the
-        // quotient of the running maximum (division is monotone): two divisions per pair instead of one per
-        // level, the same values bit for bit.
+        // quotient of the running maximum (division is monotone), and the running maximum of f_N^2 does not
+        // depend on the frequency: pf2 holds it (prefix_max_in_place, once per profile).  It is non-decreasing,
+        // so the first level above 1 comes from a 64-ary search - two LDS round trips for any K <= 4096 - and
+        // the maximum below it is the entry before: two divisions per pair, no scan, no wave reduction, the
+        // same values bit for bit.
         const double ulp_half = f2 * 0x1p-53;
+        const int stride = (K + 63) >> 6;
+        const int probe = min((lane + 1) * stride - 1, K - 1);
+        const unsigned long long coarse = __ballot((pf2[probe] - f2) > ulp_half);
         double amax = -__builtin_inf(), a_star = 0.0;
-        for (int base = 0; base < K; base += 64) {
-            const int k = base + lane;
-            const double a = (k < K) ? pf2[k] : -__builtin_inf();
-            const unsigned long long hit = __ballot((a - f2) > ulp_half);
-            if (hit) {
-                const int first = __ffsll((long long)hit) - 1;
-                kstar = base + first;
-                a_star = __shfl(a, first);
-                if (lane < first) amax = fmax(amax, a);
-                break;
-            }
-            amax = fmax(amax, a);
+        if (coarse) {
+            const int lo = (__ffsll((long long)coarse) - 1) * stride;
+            const int k = min(lo + lane, K - 1);
+            const unsigned long long fine = __ballot(lane < stride && (pf2[k] - f2) > ulp_half);
+            kstar = lo + __ffsll((long long)fine) - 1;
+            a_star = pf2[kstar];
+            if (kstar > 0) amax = pf2[kstar - 1];
+        } else {
+            amax = pf2[K - 1];
         }
-        amax = wave_max(amax);
         lmax = amax / f2;                       // :136; -inf stays -inf (no level below the first hit)
         col_star = a_star / f2;
     } else {
@@ -268,7 +271,7 @@ __device__ __forceinline__ bool reflection_height(const Node* __restrict__ nodes
             lmax = fmax(lmax, col);
         }
     }
-    const double below = wave_max(lmax);        // running maximum at level kstar-1
+    const double below = (MODE == PRHF_KMODE_O) ? lmax : wave_max(lmax);        // running maximum at level kstar-1
     double h;
     if (kstar == K) {
         if (!(below >= 1.0)) return false;      // never reaches the cutoff (:399)
@@ -295,6 +298,7 @@ struct BlockInfo {
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
     int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0); 0: some use sin()
+    int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
     double inv_step;  // 1 / level spacing (uniform grids)
@@ -373,6 +377,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     info.unmag = 0;
     info.uniform = 0;
     info.poly_angle = 0;
+    info.n_cand = -1;
     info.a0 = 0.0;
     info.inv_w = 0.0;
     info.inv_step = 0.0;
@@ -895,6 +900,76 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     return wave_sum(acc);
 }
 
+// In-place inclusive running maximum of v[0..K) by the whole workgroup (O-mode level search).  Every thread owns
+// ceil(K / THREADS) consecutive levels; wave scan of the thread maxima, wave totals through `red`.
+template <int THREADS>
+__device__ __forceinline__ void prefix_max_in_place(double* v, int K, double* red) {
+    constexpr int W = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (K + THREADS - 1) / THREADS;
+    const int base = tid * per;
+    double mine = -__builtin_inf();
+    for (int i = 0; i < per; ++i)
+        if (base + i < K) mine = fmax(mine, v[base + i]);
+    double inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(inc, off);
+        if (lane >= off) inc = fmax(inc, o);
+    }
+    double before = __shfl_up(inc, 1);             // maximum of the lower lanes' levels
+    if (lane == 0) before = -__builtin_inf();
+    if (lane == 63) red[wave] = inc;               // (rows 0..3 of `red` were phase-1 scratch of stage_profile: free now)
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+        if (w < wave) before = fmax(before, red[w]);
+    for (int i = 0; i < per; ++i)
+        if (base + i < K) {
+            before = fmax(before, v[base + i]);
+            v[base + i] = before;
+        }
+    __syncthreads();
+}
+
+// The frequencies of this profile that may reflect, in ascending index order, as a list in LDS; the others -
+// those for which the bound of pair_reflects says "escapes for certain" - get their NaN here, with coalesced
+// stores, and never become work items.  Whole workgroup; returns the list length (wave-uniform).
+template <int THREADS>
+__device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg, const double* keep,
+                                               long long pair_base, unsigned short* cand, int* cand_count) {
+    constexpr int W = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = (int)a.n_freq;
+    const double pmax = keep[kKeepPf2Max], gmax = keep[kKeepGbMax];
+    int total = 0;
+    for (int base = 0; base < F; base += THREADS) {
+        const int f = base + tid;
+        bool may = false;
+        if (f < F) {
+            const double* row = a.ftab + 8 * (long long)f;
+            double ub = pmax * row[4];
+            if (sg.mode == PRHF_KMODE_X) ub = ub + gmax * row[5];
+            may = !(ub < 1.0 - 1e-9);
+            if (!may) a.out[sg.out_off + pair_base + f] = qnan();      // never reaches the cutoff (:399)
+        }
+        const unsigned long long mask = __ballot(may);
+        if (lane == 0) cand_count[wave] = __popcll(mask);
+        __syncthreads();
+        int at = total, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int n = cand_count[w];
+            if (w < wave) at += n;
+            chunk += n;
+        }
+        if (may) cand[at + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)f;
+        __syncthreads();
+        total += chunk;
+    }
+    return uniform(total);
+}
+
 // Per-frequency scalars of a pair.  Long launches read them from a table built once per launch
 // (freq_table_kernel: F x 8 doubles, one 64-byte row per frequency, fetched with the wave-uniform index);
 // short ones compute them in place.  f_hz, f2 are the reference's own values (:491, f**2); cX, cY2 only
@@ -931,7 +1006,7 @@ template <int MODE>
 __device__ __forceinline__ bool pair_reflects(const Node* nodes, const double* pf2, const double* gb,
                                               const BlockInfo& info, const double* keep, const PairFreq& pf,
                                               int lane, double* h_out) {
-    if (info.K > 1) {
+    if (info.K > 1 && info.n_cand < 0) {           // (a candidate list has applied this bound already)
         double ub = keep[kKeepPf2Max] * pf.inv_f2;
         if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] * pf.inv_f;
         if (uniform((int)(ub < 1.0 - 1e-9))) return false;
@@ -959,15 +1034,16 @@ __device__ __forceinline__ double one_level_term(const Node* nodes, const BlockI
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
-                                          const BlockInfo& info, long long prof_local, int block_in_prof,
-                                          int blocks_per_prof, int* item_next, const double* red) {
+                                          const unsigned short* cand, const BlockInfo& info, long long prof_local,
+                                          int block_in_prof, int blocks_per_prof, int* item_next, const double* red) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63;
     const double* keep = kept_scalars<THREADS>(red);
     const double wc = uniform(sg.well_conditioned);
     const int F = uniform((int)a.n_freq);
     const int C = uniform(sg.chunks);
-    const int T = F * C;                           // < 2^31: n_freq <= 2^20, chunks <= n_points / 256
+    // items: (frequency, chunk), or - unchunked long launches - the entries of the candidate list
+    const int T = info.n_cand >= 0 ? info.n_cand : F * C;      // < 2^31: n_freq <= 2^20, chunks <= n_points / 256
     const double* mult = a.mult + sg.mult_off;
     const double2* pairs = (a.pairs && sg.lean) ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
@@ -986,7 +1062,9 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
     };
     for (int t = next_item(); t < T; t = next_item()) {
         int f = t, c = 0;
-        if (C > 1) {                               // (unchunked launches spare the integer division)
+        if (info.n_cand >= 0) {
+            f = uniform((int)cand[t]);
+        } else if (C > 1) {                        // (unchunked launches spare the integer division)
             f = t % F;
             c = t / F;
         }
@@ -1036,9 +1114,9 @@ constexpr int kTail = 16;
 template <int MODE, int THREADS>
 __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& sg, const Node* nodes,
                                                  const double* pf2, const double* gb,
-                                                 const unsigned short* hint, const BlockInfo& info,
-                                                 long long prof_local, int block_in_prof, int blocks_per_prof,
-                                                 int* item_next, const double* red) {
+                                                 const unsigned short* hint, const unsigned short* cand,
+                                                 const BlockInfo& info, long long prof_local, int block_in_prof,
+                                                 int blocks_per_prof, int* item_next, const double* red) {
     constexpr int W = THREADS / 64;
     constexpr int TIER = 0;
     const int lane = threadIdx.x & 63;
@@ -1046,7 +1124,8 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
     const double* keep = kept_scalars<THREADS>(red);
     const double wc = uniform(sg.well_conditioned);
     const int F = uniform((int)a.n_freq);
-    const int T = (F + 3) >> 2;
+    const int count = info.n_cand >= 0 ? info.n_cand : F;      // frequencies to evaluate (candidate list or all)
+    const int T = (count + 3) >> 2;
     const int n = uniform(sg.n_points);
     const double* mult = a.mult + sg.mult_off;
     const double2* pairs = reinterpret_cast<const double2*>(a.pairs) + sg.mult_off;
@@ -1066,15 +1145,18 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
     const double alt_min = keep[kKeepAltMin];
     const int ti = n - kTail + (lane & 15);        // this lane's tail point
     for (int t = next_item(); t < T; t = next_item()) {
-        const int f0 = t << 2;
-        // per-lane parameters of the pair whose tail point this lane evaluates
+        const int e0 = t << 2;
+        // per-lane parameters of the pair whose tail point this lane evaluates; my_sum: what the four lanes
+        // l, l ^ 16, l ^ 32, l ^ 48 accumulated in that pair's main loop (the tail's reduction below finishes the sum)
         double my_fhz = 1.0, my_f2 = 1.0, my_h = 0.0, my_sum = 0.0;
+        int my_f = -1;
         unsigned tail_mask = 0;                    // bit q: pair q takes part in the shared tail iteration
         double my_done = qnan();                   // result of this lane's pair if it does not (NaN: escapes)
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
-            const int f = f0 + q;
-            if (f >= F || info.bad) continue;
+            if (e0 + q >= count) continue;
+            const int f = info.n_cand >= 0 ? uniform((int)cand[e0 + q]) : e0 + q;
+            if (sub == q) my_f = f;
             const PairFreq pf = pair_freq(a, f);
             double h = 0.0;
             if (!pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h)) continue;   // (K > 1 on this path)
@@ -1090,10 +1172,12 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
                 if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
                 else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
 #undef PRHF_LEAN
-                const double s = wave_sum(r.acc);
-                if (uniform(r.first) == n - kTail && uniform((int)(__builtin_fabs(s) <= 1.7976931348623157e308))) {
+                if (uniform(r.first) == n - kTail &&
+                    !uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
                     shared = true;
                     tail_mask |= 1u << q;
+                    double s = r.acc + __shfl_xor(r.acc, 32);
+                    s = s + __shfl_xor(s, 16);
                     if (sub == q) { my_fhz = pf.f_hz; my_f2 = pf.f2; my_h = h; my_sum = s; }
                 }
             }
@@ -1129,15 +1213,15 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
             index_faithful<MODE>(X, Y, psi, &mu, &mup);
             double term = mup * dh;                                              // :288
             if (!(live && term == term)) term = 0.0;                             // nansum
-            // sum over the 16 lanes of each pair
+            // sum over the 16 lanes of each pair: its tail terms and its main loop's four-lane partial sums
+            double total = term + my_sum;
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) term = term + __shfl_xor(term, off);
-            const double total = my_sum + term;
+            for (int off = 8; off >= 1; off >>= 1) total = total + __shfl_xor(total, off);
             shared_vh = (total != 0.0) ? total + alt_min : qnan();               // :290-292
         }
         // lanes 0, 16, 32, 48 store their pair's result
-        if ((lane & 15) == 0 && f0 + sub < F)
-            a.out[sg.out_off + pair_base + f0 + sub] = ((tail_mask >> sub) & 1u) ? shared_vh : my_done;
+        if ((lane & 15) == 0 && my_f >= 0)
+            a.out[sg.out_off + pair_base + my_f] = ((tail_mask >> sub) & 1u) ? shared_vh : my_done;
     }
 }
 
@@ -1146,12 +1230,18 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
 // Returns the wall clock at the end of staging in -DPRHF_TRACE builds (0 otherwise).
 template <int TIER, int THREADS>
 __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
-                                          unsigned short* hint, double* red, long long prof_local,
-                                          int block_in_prof, int blocks_per_prof, int* item_next) {
+                                          unsigned short* hint, unsigned short* cand, int* cand_count, double* red,
+                                          long long prof_local, int block_in_prof, int blocks_per_prof,
+                                          int* item_next) {
     const long long p = sg.prof_begin + prof_local;
-    const BlockInfo info = stage_profile<TIER, THREADS>(
+    BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
+    if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
+    info.n_cand = -1;
+    if (a.ftab && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
+        info.n_cand = list_candidates<THREADS>(a, sg, kept_scalars<THREADS>(red), prof_local * a.n_freq, cand,
+                                               cand_count);
 #ifdef PRHF_TRACE
     const unsigned long long t_staged = wall_clock64();
 #else
@@ -1164,16 +1254,16 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     if (TIER == 0 && sg.group == 4 && !info.bad && !info.unmag && info.poly_angle != 0 && info.K > 1) {
         // short grids, default O-mode arithmetic: four frequencies per item (run_items_tail16)
         if (sg.mode == PRHF_KMODE_O)
-            run_items_tail16<PRHF_KMODE_O, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+            run_items_tail16<PRHF_KMODE_O, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                     blocks_per_prof, item_next, red);
         else
-            run_items_tail16<PRHF_KMODE_X, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+            run_items_tail16<PRHF_KMODE_X, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                     blocks_per_prof, item_next, red);
     } else if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, info, prof_local, block_in_prof,
+        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     return t_staged;
 }
@@ -1187,8 +1277,8 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     double* pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
     double* gb = pf2 + n_alt;
     unsigned short* hint = reinterpret_cast<unsigned short*>(gb + n_alt);
-    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
-                                            kHintBuckets * sizeof(unsigned short));
+    unsigned short* cand = hint + kHintBuckets;
+    double* red = reinterpret_cast<double*>(cand + PRHF_MAX_CAND);
 
     // Long launches are persistent: as many workgroups as the device keeps resident, each pulling the
     // next block of work from a queue when it finishes one.  (Left to the hardware dispatcher, the
@@ -1197,6 +1287,7 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     // the same uniform test, so the grid always drains.
     __shared__ long long next_bid;
     __shared__ int item_next;
+    __shared__ int cand_count[PRHF_BLOCK_THREADS / 64 + 1];
     long long bid = blockIdx.x;
     for (;;) {
         if (threadIdx.x == 0) item_next = 0;   // ordered before its first use by the barriers of stage_profile
@@ -1219,8 +1310,10 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         const int block_in_prof = (int)(lb % bpp);
 
         const unsigned long long t_staged = (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-            ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next)
-            : run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, red, prof_local, block_in_prof, bpp, &item_next);
+            ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+                                    &item_next)
+            : run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+                                    &item_next);
         (void)t_staged;
 #ifdef PRHF_TRACE
         if (a.trace && (threadIdx.x & 63) == 0) {
@@ -1467,14 +1560,14 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
     double* pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
     double* gb = pf2 + n_alt;
     unsigned short* hint = reinterpret_cast<unsigned short*>(gb + n_alt);
-    double* red = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(hint) +
-                                            kHintBuckets * sizeof(unsigned short));
+    double* red = reinterpret_cast<double*>(hint + kHintBuckets + PRHF_MAX_CAND);
     const int f = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const double one_mhz = 1.0;     // stage_profile only needs a frequency column for the isotropic test
     const BlockInfo info = stage_profile<0, THREADS>(a.den, a.bmag, a.bpsi, a.alt, &one_mhz, 0, n_alt, nodes,
                                                      pf2, gb, hint, red);
     if (threadIdx.x == 0 && info.bad) atomicOr(a.status, (unsigned)info.bad);
+    if (a.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     const double f_hz = a.freq_hz[f];
     double h = qnan();
     int reflects = 0;
