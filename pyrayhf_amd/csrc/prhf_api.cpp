@@ -44,6 +44,7 @@ int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grid
 double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
 int kTailGroupMinPoints = 81;             // PRHF_TAIL_GROUP_MIN / _MAX: grids of this many points take four frequencies per item
 int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 of them are ill conditioned: nothing to share)
+int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
@@ -394,6 +395,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 #endif
     a.n_blocks = blocks;
+    a.no_candidates = kNoCandidates;
     long long grid_blocks = blocks;
     if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
         a.queue = c->d_status + 1;
@@ -460,6 +462,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         if (v >= 64) kTargetWaves = v;
     }
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
+    if (const char* nc = std::getenv("PRHF_NO_CANDIDATES")) kNoCandidates = std::atoi(nc) != 0;
     if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
     if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(2, std::atoi(lm));
     if (const char* g0 = std::getenv("PRHF_TAIL_GROUP_MIN")) kTailGroupMinPoints = std::max(81, std::atoi(g0));

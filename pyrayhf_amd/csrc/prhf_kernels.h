@@ -72,6 +72,7 @@ struct KArgs {
     unsigned long long* trace;       // -DPRHF_TRACE builds: (start, end) wall clock of every wave, else unused
     long long n_freq, n_alt, prof_stride, alt_stride;
     int n_segs;
+    int no_candidates;               // PRHF_NO_CANDIDATES=1 (A/B runs): every frequency is a work item, none is pre-filtered
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 

@@ -1239,7 +1239,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     info.n_cand = -1;
-    if (a.ftab && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
+    if (a.ftab && !a.no_candidates && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
         info.n_cand = list_candidates<THREADS>(a, sg, kept_scalars<THREADS>(red), prof_local * a.n_freq, cand,
                                                cand_count);
 #ifdef PRHF_TRACE

@@ -122,3 +122,66 @@ def test_config5_mixed_worklist(lib):
     got = lib.vertical_forward_operator(freq[::8], den[4000:4003], bmag[4000:4003], bpsi[4000:4003], alt, "X", 2000)
     assert_x_mode(got, want)
     assert_x_mode(vh[4000:4003, ::8], want)
+
+
+def test_config4_all_100000_profiles_on_one_gpu(lib):
+    """BASELINE config 4 at its full profile count in ONE launch on one GPU (1.5 GB of inputs, 205 MB of output):
+    what the 8-GPU run must reproduce.  Every eighth of it - the shard rank r evaluates at N = 8 - evaluated alone
+    must equal the same rows of the full launch bit for bit, so the all-gather of the shards IS this array."""
+    import torch
+    from pyrayhf_amd import dist as pdist, synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(100000, 20260004)
+    freq = synth.sounder_frequencies(4)
+    dev = torch.device("cuda:0")
+    t = {k: torch.as_tensor(v, device=dev) for k, v in (("freq", freq), ("alt", alt), ("den", den), ("bmag", bmag), ("bpsi", bpsi))}
+    full = lib.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", 20000)
+    assert full.shape == (100000, 256)
+    ms = lib.last_kernel_ms(0)
+    for rank in (0, 3, 7):
+        lo, hi = pdist.shard_bounds(100000, 8, rank)
+        assert hi - lo == 12500
+        part = lib.vertical_forward_operator(t["freq"], t["den"][lo:hi], t["bmag"][lo:hi], t["bpsi"][lo:hi], t["alt"], "X", 20000)
+        assert torch.equal(torch.nan_to_num(part, nan=-1.0), torch.nan_to_num(full[lo:hi], nan=-1.0)), rank
+    vh = full.cpu().numpy()
+    fin = np.isfinite(vh)
+    assert 0.50 < fin.mean() < 0.53
+    # (virtual heights grow without bound towards a layer's critical frequency: among 13 million reflecting pairs a
+    # few exceed the 5000 km that bounds the 12 500-profile shard)
+    assert np.all(vh[fin] >= alt.min()) and np.all(vh[fin] < 1e6)
+    pick = np.sort(np.random.default_rng(44).choice(100000, 400, replace=False))
+    refl = reflecting_mask(freq, den[pick], bmag[pick], "X")
+    assert not (fin[pick] & ~refl).any()
+    print(f"config 4, 100 000 x 256 on one GPU: {ms:.1f} ms, {vh.size / ms * 1e3:.3e} integrals/s, crc32 {checksum(vh):08x}, "
+          f"reflecting {fin.mean():.4f}")
+
+
+def test_config5_all_50000_profiles_on_one_gpu(lib):
+    """BASELINE config 5 at its full size as ONE work-list launch, and the same list cut for 8 ranks
+    (dist.shard_segments) evaluated rank by rank on this GPU and put back with the rows shard_segments names:
+    bit-identical to the single launch - the N = 8 gather has a single-GPU answer to be compared with."""
+    import torch
+    from bench import CONFIG5_SEGMENTS
+    from pyrayhf_amd import dist as pdist, synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005)
+    freq = synth.sounder_frequencies(5)
+    dev = torch.device("cuda:0")
+    t = {k: torch.as_tensor(v, device=dev) for k, v in (("freq", freq), ("alt", alt), ("den", den), ("bmag", bmag), ("bpsi", bpsi))}
+    full = lib.vertical_forward_operator_mixed(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], CONFIG5_SEGMENTS)
+    ms = lib.last_kernel_ms(0)
+    assert full.shape == (50000, 512)
+    rebuilt = torch.full_like(full, float("nan"))
+    for rank in range(8):
+        rows, local = pdist.shard_segments(CONFIG5_SEGMENTS, 8, rank)
+        assert rows.size == 6250
+        idx = torch.as_tensor(rows, device=dev)
+        part = lib.vertical_forward_operator_mixed(t["freq"], t["den"][idx], t["bmag"][idx], t["bpsi"][idx], t["alt"], local)
+        rebuilt[idx] = part
+    assert torch.equal(torch.nan_to_num(rebuilt, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
+    vh = full.cpu().numpy()
+    fin = np.isfinite(vh)
+    assert 0.45 < fin.mean() < 0.60
+    for p0, p1, mode, n in CONFIG5_SEGMENTS:
+        pick = np.arange(p0, p1, max(1, (p1 - p0) // 100))
+        refl = reflecting_mask(freq, den[pick], bmag[pick], mode)
+        assert not (fin[pick] & ~refl).any()
+    print(f"config 5, 50 000 x 512 mixed on one GPU: {ms:.1f} ms, {vh.size / ms * 1e3:.3e} integrals/s, crc32 {checksum(vh):08x}")
