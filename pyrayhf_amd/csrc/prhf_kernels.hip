@@ -37,6 +37,9 @@ constexpr double kUnmagTol = 1e-12;                 // library.py:163
 constexpr double kLightKmS = 299792.458;            // library.py:70
 constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
 constexpr double kQuadAngle = 4e-5;                 // ... and below which its economised quadratic errs < 1.4e-15
+constexpr double kLinTol = 1e-10;                   // a segment's quadratic term may be economised away when that costs
+                                                    // < 1e-10 in sin^2 psi: an offset of 4e-11 everywhere moves a virtual
+                                                    // height by <= 1.6e-11 (measured), an equioscillating one by less
 
 // One bottomside level = the left end of one np.interp segment [alt_j, alt_j+1): den, b are the
 // level values, sden, sb the np.interp slopes, and the abscissa is dz = z - alt_j.
@@ -297,7 +300,7 @@ struct BlockInfo {
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
-    int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0); 0: some use sin()
+    int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too); 0: some use sin()
     int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
@@ -389,7 +392,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
     double bmax = 0.0, pmax = 0.0;
-    int neg = 0, ragged = 0, trig = 0, cubic = 0;
+    int neg = 0, ragged = 0, trig = 0, cubic = 0, quadratic = 0;
     for (int k = tid; k <= K; k += THREADS) {
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
@@ -436,6 +439,15 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                 nd.u1 = nd.u1 - nd.u3 * (L * L) * (9.0 / 16.0);
                 nd.u2 = nd.u2 + nd.u3 * L * 1.5;
                 nd.u3 = 0.0;
+                // ... and x^2 ~ L x - L^2/8 on [0, L], error |u2| L^2 / 8: for fields that turn by ~1e-5 rad per
+                // level (PyIRI) the quadratic term is below kLinTol and the main loop saves another FMA
+                if (fabs(nd.u2) * (L * L) * 0.125 <= kLinTol) {
+                    nd.u0 = nd.u0 - nd.u2 * (L * L) * 0.125;
+                    nd.u1 = nd.u1 + nd.u2 * L;
+                    nd.u2 = 0.0;
+                } else {
+                    quadratic = 1;
+                }
             } else {
                 cubic = 1;
             }
@@ -455,7 +467,8 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     pmax = wave_max(pmax);
     neg = __any(neg) ? 1 : 0;
     ragged = __any(ragged) ? 1 : 0;
-    trig = __any(trig) ? 1 : (__any(cubic) ? 2 : 0);   // 1: some segment needs sin(), 2: some segment keeps its cubic
+    // 1: some segment needs sin(), 2: some segment keeps its cubic, 3: some keeps its quadratic, 0: all linear
+    trig = __any(trig) ? 1 : (__any(cubic) ? 2 : (__any(quadratic) ? 3 : 0));
     if (lane == 0) {
         red[4 * W + wave] = bmax;
         red[5 * W + wave] = (double)neg;
@@ -474,7 +487,10 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         bmax = fmax(bmax, red[4 * W + w]);
         pmax = fmax(pmax, red[8 * W + w]);
         neg |= (int)red[5 * W + w];
-        trig = (trig == 1 || (int)red[6 * W + w] == 1) ? 1 : (trig | (int)red[6 * W + w]);
+        {
+            const int o = (int)red[6 * W + w];          // order of need: sin() 1 > cubic 2 > quadratic 3 > linear 0
+            trig = (trig == 1 || o == 1) ? 1 : ((trig == 2 || o == 2) ? 2 : ((trig == 3 || o == 3) ? 3 : 0));
+        }
         ragged |= (int)red[7 * W + w];
     }
     bmax = uniform(bmax);
@@ -488,7 +504,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
     info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    info.poly_angle = trig == 1 ? 0 : (trig == 2 ? 1 : 2);
+    info.poly_angle = trig == 1 ? 0 : (trig == 2 ? 1 : (trig == 3 ? 2 : 3));
     // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
     const double a0 = uniform(nodes[0].alt);
     const double span = uniform(nodes[K - 1].alt) - a0;
@@ -624,10 +640,11 @@ __device__ __forceinline__ double group_index_lean(double den, double b, double 
 // D > 0, q = X(1-X)/D >= 0, so the mu > 1 cliff (:238) cannot trigger.
 // CHECK: also report (in `viol`, a lane mask) the points whose 1 - X is not above `wc` - the default O-mode
 // arithmetic only accepts wave-iterations where the reduced algebra is safe.
-// QUAD: every segment of the profile carries the economised quadratic (u3 = 0, not read).
+// POLY: degree of the sin^2 psi polynomial every segment of the profile carries: 3 cubic, 2 economised
+// quadratic (u3 = 0, not read), 1 economised linear (u2 = 0 too, not read).
 // HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
-template <int MODE, bool CHECK, bool QUAD, bool HINT>
+template <int MODE, bool CHECK, int POLY, bool HINT>
 __device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX, double khcX,
                                             double cY2, double acc, double wc, unsigned long long& viol,
                                             unsigned nodes_v, unsigned hint_v) {
@@ -661,7 +678,8 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     double off = *(LdsDouble)(pn + 8);
     const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48);
     vec2 r_ub;
-    if (QUAD) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
+    if (POLY == 1) { r_ub.x = 0.0; r_ub.y = 0.0; }
+    else if (POLY == 2) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
     else r_ub = *(LdsVec2)(pn + 64);
     double2 dd = make_double2(r_dd.x, r_dd.y);                     // den, sden
     double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
@@ -677,7 +695,48 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     if (HINT) x = fmax(x, 0.0);                                 // the table walk guarantees alt[j] <= z: rounding only
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
-    const double S2 = QUAD ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y));
+    const double S2 = POLY == 1 ? ua.x + x * ua.y
+                    : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
+    double a;
+    const double mup = group_index_lean<MODE>(den, b, S2, cX, khcX, cY2, &a);
+    if (CHECK) viol |= __ballot(!(a > wc));
+    return __builtin_fma(mup, g.y, acc);
+}
+
+// The top segment of a pair in m: about half of a long grid's points lie between the last level below the
+// reflection height and the reflection height itself (the stretched grid is dense there).  For those points the
+// node is the same for every lane and every trip, so the three interpolants become polynomials in m with
+// wave-uniform coefficients - no segment index, no LDS read, no abscissa: 36 instructions per point instead of 40.
+struct TopSegment {
+    double d0, d1;          // den  = d0 + d1 m
+    double b0, b1;          // |B|  = b0 + b1 m
+    double q0, q1, q2, q3;  // sin^2 psi = q0 + m (q1 + m (q2 + m q3))
+};
+__device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, double span) {
+#pragma clang fp contract(fast)
+    typedef __attribute__((address_space(3))) const double* LdsDouble;
+    const LdsDouble nd = (LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
+    // Node = {alt, off, den, sden, b, sb, u0, u1, u2, u3, psi, spsi}
+    const double o = nd[1], s = span;                          // x = s m + o
+    const double den = nd[2], sden = nd[3], b = nd[4], sb = nd[5], u0 = nd[6], u1 = nd[7], u2 = nd[8], u3 = nd[9];
+    TopSegment t;
+    t.d0 = den + sden * o;  t.d1 = sden * s;
+    t.b0 = b + sb * o;      t.b1 = sb * s;
+    t.q0 = u0 + o * (u1 + o * (u2 + o * u3));
+    t.q1 = s * (u1 + o * (2.0 * u2 + 3.0 * o * u3));
+    t.q2 = (s * s) * (u2 + 3.0 * o * u3);
+    t.q3 = (s * s * s) * u3;
+    return t;
+}
+template <int MODE, bool CHECK, int POLY>
+__device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, double cX, double khcX, double cY2,
+                                                double acc, double wc, unsigned long long& viol) {
+#pragma clang fp contract(fast)
+    const double m0 = g.x;
+    const double den = t.d1 * m0 + t.d0;
+    const double b = t.b1 * m0 + t.b0;
+    const double S2 = POLY == 1 ? t.q0 + m0 * t.q1
+                    : (POLY == 2 ? t.q0 + m0 * (t.q1 + m0 * t.q2) : t.q0 + m0 * (t.q1 + m0 * (t.q2 + m0 * t.q3)));
     double a;
     const double mup = group_index_lean<MODE>(den, b, S2, cX, khcX, cY2, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
@@ -700,7 +759,9 @@ struct LeanResult {
 
 // CHECK (default O-mode arithmetic): stop in front of the first trip that holds a point with
 // 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
-template <int MODE, bool CHECK, bool QUAD, bool HINT>
+// TOP: with the top-segment phase (long grids on a uniform altitude grid); the short-grid callers use the
+// variant without it, which needs 24 fewer vector registers around the call.
+template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
 __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds,
                                                           const double2* __restrict__ pairs, int first, int end,
                                                           int last_special, double span, double a0, double kj,
@@ -727,8 +788,8 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double2*>(pairs), 0, 0x7fffffff, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto grid_at = [&](int i) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
         double2 g;
         __builtin_memcpy(&g, &v, sizeof g);
@@ -736,31 +797,94 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     };
     // whole iterations: all 64 points below `end` and none of them the special last point
     const int whole_end = first + (((last_special >= 0 ? last_special : end) - first) & ~63);
+    // Long loops on a uniform grid: from grid point i_top on, every point lies in the segment of the last one
+    // (lean_step_top).  i_top = first i with m_i >= j_top / kj, found in the (monotone) pair table by a 64-ary
+    // search: three rounds of one load and one ballot for 20 000 points.
+    int split = whole_end;                             // [first, split): indexed steps, [split, ...): top-segment steps
+    TopSegment top;
+    __builtin_memset(&top, 0, sizeof top);
+    bool top_phase = false;
+    if (TOP && !HINT && end - first >= 1024) {
+        const int i_last = (last_special >= 0 ? last_special : end - 1);
+        const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, i_last * (int)sizeof(double2), 0);
+        double2 gl;
+        __builtin_memcpy(&gl, &vl, sizeof gl);
+        const int j_top = uniform((int)(gl.x * kj));
+        const double m_star = uniform((double)j_top / kj);
+        int lo = first, hi = i_last + 1;               // the answer lies in [lo, hi): m[hi - 1] >= m_star
+        bool found = uniform((int)(gl.x >= m_star)) != 0;
+        while (found && hi - lo > 1) {
+            const int stride = (hi - lo + 63) >> 6;
+            const int probe = min(lo + (lane + 1) * stride - 1, hi - 1);
+            const u32x4 vp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)probe * (unsigned)sizeof(double2), 0, 0);
+            double2 gp;
+            __builtin_memcpy(&gp, &vp, sizeof gp);
+            const unsigned long long hit = __ballot(gp.x >= m_star);
+            if (!hit) { found = false; break; }
+            const int L = __ffsll((long long)hit) - 1;
+            const int nlo = lo + L * stride;
+            hi = min(nlo + stride, hi);
+            lo = nlo;
+        }
+        if (found) {
+            const int aligned = first + ((lo - first + 63) & ~63);
+            if (aligned + 128 <= whole_end) {          // worth a second loop
+                split = aligned;
+                top = top_segment(nodes_v, j_top, span);
+                top_phase = true;
+            }
+        }
+    }
     double accm = 0.0;                                 // sum of mu' * weight
     unsigned long long viol = 0;
     double2 g0 = grid_at(first);
     // two wave-iterations per trip so that the prefetch registers swap roles without moves
-    for (; first + 128 <= whole_end; first += 128) {
+    for (; first + 128 <= split; first += 128) {
         const double2 g1 = grid_at(first + 64);
         if (!CHECK) {
-            accm = lean_step<MODE, false, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, QUAD, HINT>(g1, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
         } else {
-            const double a1 = lean_step<MODE, true, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, QUAD, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol, nodes_v, hint_v);
+            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol, nodes_v, hint_v);
             if (viol) break;                           // neither half of this trip counts
             accm = a2;
             g0 = g2;
         }
     }
-    if (!(CHECK && viol) && first + 64 <= whole_end) { // odd whole wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+    if (!(CHECK && viol) && first + 64 <= split) {     // odd whole wave-iteration left over
+        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
             g0 = grid_at(first);
+        }
+    }
+    if (TOP && top_phase && !(CHECK && viol)) {        // the same two loops over the top segment
+        for (; first + 128 <= whole_end; first += 128) {
+            const double2 g1 = grid_at(first + 64);
+            if (!CHECK) {
+                accm = lean_step_top<MODE, false, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+                g0 = grid_at(first + 128);
+                accm = lean_step_top<MODE, false, POLY>(g1, top, cX, khcX, cY2, accm, wc, viol);
+            } else {
+                const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+                const double2 g2 = grid_at(first + 128);
+                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, cY2, a1, wc, viol);
+                if (viol) break;
+                accm = a2;
+                g0 = g2;
+            }
+        }
+        if (!(CHECK && viol) && first + 64 <= whole_end) {
+            const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+            if (!(CHECK && viol)) {
+                accm = a1;
+                first += 64;
+                g0 = grid_at(first);
+            }
         }
     }
     if (!(CHECK && viol) && first < end) {             // partial wave-iteration: at most 64 points left
@@ -769,8 +893,15 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         const bool live = idx < end;
         double2 g = g0;
         if (is_last) g.y = kBackoff / span;            // :415-416: the last thickness is 1e-6 km
-        if (!live) g = make_double2(0.0, 0.0);         // an idle lane re-evaluates grid point 0 with weight 0
-        const double a1 = lean_step<MODE, CHECK, QUAD, HINT>(g, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+        double a1;
+        if (TOP && top_phase) {
+            // an idle lane re-evaluates this iteration's first point (lane 0 is always live) with weight 0
+            if (!live) g = make_double2(uniform(g0.x), 0.0);
+            a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, khcX, cY2, accm, wc, viol);
+        } else {
+            if (!live) g = make_double2(0.0, 0.0);     // an idle lane re-evaluates grid point 0 with weight 0
+            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+        }
         if (!(CHECK && viol)) {
             accm = a1;
             first = end;
@@ -826,12 +957,15 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
             const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
             const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
-            const bool quad = info.poly_angle == 2;
+            const int poly = 4 - info.poly_angle;           // degree: 3 cubic, 2 quadratic, 1 linear
             LeanResult r;
-#define PRHF_LEAN(Q, H) lean_loop<MODE, TIER == 0, Q, H>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
-                                                           span, a0, kj, cX, cY2, well_conditioned)
-            if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
-            else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
+#define PRHF_LEAN(P, H, T) lean_loop<MODE, TIER == 0, P, H, T>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
+                                                                 span, a0, kj, cX, cY2, well_conditioned)
+#define PRHF_LEAN_POLY(H, T) (poly == 1 ? PRHF_LEAN(1, H, T) : (poly == 2 ? PRHF_LEAN(2, H, T) : PRHF_LEAN(3, H, T)))
+            if (by_hint) r = PRHF_LEAN_POLY(true, false);
+            else if (lean_end - first >= 1024) r = PRHF_LEAN_POLY(false, true);
+            else r = PRHF_LEAN_POLY(false, false);
+#undef PRHF_LEAN_POLY
 #undef PRHF_LEAN
             // a NaN term (mu^2 < 0 by rounding, :233) or an infinite one (mu^2 == 0) poisons the lane sum: then
             // the whole range goes through the generic loop, whose nansum drops such terms one by one (:288)
@@ -1141,7 +1275,7 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
     typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
     const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
     const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
-    const bool quad = info.poly_angle == 2;
+    const int poly = 4 - info.poly_angle;              // degree of the sin^2 psi polynomials: 3, 2 or 1
     const double alt_min = keep[kKeepAltMin];
     const int ti = n - kTail + (lane & 15);        // this lane's tail point
     for (int t = next_item(); t < T; t = next_item()) {
@@ -1167,10 +1301,10 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
             bool shared = false;
             if (span > 0.0 && in_table) {
                 LeanResult r;
-#define PRHF_LEAN(Q, H) lean_loop<MODE, true, Q, H>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
-                                                      pf.cX, pf.cY2, wc)
-                if (by_hint) r = quad ? PRHF_LEAN(true, true) : PRHF_LEAN(false, true);
-                else r = quad ? PRHF_LEAN(true, false) : PRHF_LEAN(false, false);
+#define PRHF_LEAN(P, H) lean_loop<MODE, true, P, H, false>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
+                                                             pf.cX, pf.cY2, wc)
+                if (by_hint) r = poly == 1 ? PRHF_LEAN(1, true) : (poly == 2 ? PRHF_LEAN(2, true) : PRHF_LEAN(3, true));
+                else r = poly == 1 ? PRHF_LEAN(1, false) : (poly == 2 ? PRHF_LEAN(2, false) : PRHF_LEAN(3, false));
 #undef PRHF_LEAN
                 if (uniform(r.first) == n - kTail &&
                     !uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
