@@ -218,6 +218,24 @@ int prhf_snell_spherical_f64(prhf_ctx* ctx, const double* freq_hz, const double*
                              double apex_boost, int32_t max_substeps, double* out, double* path_x, double* path_z,
                              int64_t path_stride, uint32_t flags);
 
+/*
+ * Fans of rays: many elevations per (profile, frequency).  The tracers above evaluate the Appleton-Hartree index
+ * level by level for every ray (library.py:1184-1189 / :1566-1571) although it depends on the profile and the
+ * frequency only; here the n_groups (profile, frequency) groups get their level table once (one thread per group
+ * and level) and every ray reads the table of its group: group_freq_hz[g] [Hz], group_profile_index[g] (NULL:
+ * profile 0), ray_group[r] in [0, n_groups), elevation_deg[r].  geometry 0: flat Earth (the four controls are
+ * ignored), 1: spherical Earth.  Outputs, paths, flags and errors as for the per-ray calls; the results are bit
+ * for bit those of the per-ray calls on the same rays.  PRHF_EINVAL when the level table
+ * (n_groups x (n_alt + 1) x 16 bytes) would exceed 4 GiB.
+ */
+int prhf_snell_fan_f64(prhf_ctx* ctx, int32_t geometry, const double* group_freq_hz,
+                       const int64_t* group_profile_index, int64_t n_groups, const int64_t* ray_group,
+                       const double* elevation_deg, int64_t n_rays, const double* den, const double* bmag,
+                       const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt,
+                       int64_t alt_stride_elems, int32_t mode, double earth_radius_km, double dz_target_km,
+                       double apex_boost, int32_t max_substeps, double* out, double* path_x, double* path_z,
+                       int64_t path_stride, uint32_t flags);
+
 /* Diagnostics: workgroups of the fused kernel the runtime expects to keep resident per CU for
  * profiles of n_alt levels (LDS-limited) in arithmetic tier `math`. */
 int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu);

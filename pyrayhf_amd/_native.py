@@ -76,6 +76,12 @@ _PROTOTYPES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
         ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "prhf_snell_fan_f64": (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+        ctypes.c_double, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_uint32]),
     "prhf_occupancy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -228,6 +234,14 @@ class Context:
                                                   alt, n_prof, n_alt, alt_stride, mode, float(r_e), float(dz_target),
                                                   float(apex_boost), int(max_substeps), out, path_x or None,
                                                   path_z or None, path_stride, flags)
+
+    def snell_fan(self, geometry, group_freq, group_prof, n_groups, ray_group, elev, n_rays, den, bmag, bpsi, alt, n_prof,
+                  n_alt, alt_stride, mode, r_e, dz_target, apex_boost, max_substeps, out, path_x, path_z, path_stride,
+                  flags):
+        return self._lib.prhf_snell_fan_f64(self._h, int(geometry), group_freq, group_prof or None, n_groups, ray_group,
+                                            elev, n_rays, den, bmag, bpsi, alt, n_prof, n_alt, alt_stride, mode,
+                                            float(r_e), float(dz_target), float(apex_boost), int(max_substeps), out,
+                                            path_x or None, path_z or None, path_stride, flags)
 
     def occupancy(self, n_alt, math):
         n = ctypes.c_int32(0)

@@ -98,6 +98,7 @@ struct prhf_ctx {
     DevBuf altmin;    // per-profile min(alt) for chunked slices
     DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
     DevBuf ftab;      // per-frequency scalars of a long launch
+    DevBuf levels;    // level table of a grouped tracer launch
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
     unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1] block queue of persistent launches
@@ -508,6 +509,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->altmin.p) (void)hipFree(c->altmin.p);
     if (c->pairs.p) (void)hipFree(c->pairs.p);
     if (c->ftab.p) (void)hipFree(c->ftab.p);
+    if (c->levels.p) (void)hipFree(c->levels.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_pack) (void)hipHostFree(c->h_pack);
@@ -760,13 +762,22 @@ struct SnellGeometry {
     double earth_radius_km, dz_target_km, apex_boost;
     int max_substeps;
 };
+// Grouped launch: freq_hz / profile_index describe n_groups (profile, frequency) groups and ray_group[r] names the
+// group of ray r; ungrouped: ray_group == nullptr, n_groups == 0 and freq_hz / profile_index are per ray.
 int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, const double* elevation_deg,
               const int64_t* profile_index, int64_t n_rays, const double* den, const double* bmag,
               const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt, int64_t alt_stride_elems,
-              int32_t mode, double* out, double* path_x, double* path_z, int64_t path_stride, uint32_t flags) {
+              int32_t mode, double* out, double* path_x, double* path_z, int64_t path_stride, uint32_t flags,
+              const int64_t* ray_group = nullptr, int64_t n_groups = 0) {
     if (!c) return fail(PRHF_EINVAL, "null context");
     if (!freq_hz || !elevation_deg || !den || !bmag || !bpsi || !alt || !out)
         return fail(PRHF_EINVAL, "null array pointer");
+    const bool grouped = ray_group != nullptr;
+    if (grouped && n_groups < 1) return fail(PRHF_EINVAL, "a grouped launch needs at least one group");
+    const int64_t n_keys = grouped ? n_groups : n_rays;          // entries of freq_hz / profile_index
+    const size_t level_bytes = grouped ? (size_t)n_groups * (size_t)(n_alt + 1) * 16 : 0;
+    if (level_bytes > ((size_t)4 << 30))
+        return fail(PRHF_EINVAL, "level table of %lld groups exceeds 4 GiB: trace in batches", (long long)n_groups);
     if (n_rays < 0 || n_prof < 1 || n_alt < 2 || n_alt > 3000) return fail(PRHF_EINVAL, "bad shape");
     if ((path_x == nullptr) != (path_z == nullptr)) return fail(PRHF_EINVAL, "path_x and path_z go together");
     if (path_x && path_stride < 2 * (n_alt + 1) - 1)
@@ -777,9 +788,13 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     if (n_rays == 0) return PRHF_OK;
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     if (!dev && profile_index)
-        for (int64_t r = 0; r < n_rays; ++r)
+        for (int64_t r = 0; r < n_keys; ++r)
             if (profile_index[r] < 0 || profile_index[r] >= n_prof)
                 return fail(PRHF_EINVAL, "profile_index[%lld] outside [0, n_prof)", (long long)r);
+    if (!dev && grouped)
+        for (int64_t r = 0; r < n_rays; ++r)
+            if (ray_group[r] < 0 || ray_group[r] >= n_groups)
+                return fail(PRHF_EINVAL, "ray_group[%lld] outside [0, n_groups)", (long long)r);
     ENTER_DEVICE(c->device);
     prhf::SnellArgs a;
     std::memset(&a, 0, sizeof a);
@@ -795,13 +810,18 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     const size_t prof_elems = (size_t)n_prof * (size_t)n_alt;
     const size_t alt_elems = alt_stride_elems ? prof_elems : (size_t)n_alt;
     const size_t path_elems = path_x ? (size_t)n_rays * (size_t)path_stride : 0;
+    const double* d_keyf = nullptr;
+    const long long* d_keyp = nullptr;
+    const long long* d_group = nullptr;
     if (dev) {
-        a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.freq_hz = freq_hz; a.elev_deg = elevation_deg;
-        a.prof_idx = reinterpret_cast<const long long*>(profile_index);
+        a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.elev_deg = elevation_deg;
+        d_keyf = freq_hz;
+        d_keyp = reinterpret_cast<const long long*>(profile_index);
+        d_group = reinterpret_cast<const long long*>(ray_group);
         a.out = out; a.path_x = path_x; a.path_z = path_z;
     } else {
-        const size_t elems = 3 * prof_elems + alt_elems + 3 * (size_t)n_rays + PRHF_SNELL_OUTPUTS * (size_t)n_rays +
-                             2 * path_elems;
+        const size_t elems = 3 * prof_elems + alt_elems + 2 * (size_t)n_keys + 2 * (size_t)n_rays +
+                             PRHF_SNELL_OUTPUTS * (size_t)n_rays + 2 * path_elems;
         int rc = ensure(c, c->arena, elems * 8);
         if (rc != PRHF_OK) return rc;
         double* p = static_cast<double*>(c->arena.p);
@@ -809,9 +829,10 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         double* d_bmag = p; p += prof_elems;
         double* d_bpsi = p; p += prof_elems;
         double* d_alt = p; p += alt_elems;
-        double* d_f = p; p += n_rays;
+        double* d_f = p; p += n_keys;
+        long long* d_i = reinterpret_cast<long long*>(p); p += n_keys;
         double* d_e = p; p += n_rays;
-        long long* d_i = reinterpret_cast<long long*>(p); p += n_rays;
+        long long* d_g = reinterpret_cast<long long*>(p); p += n_rays;
         double* d_out = p; p += PRHF_SNELL_OUTPUTS * (size_t)n_rays;
         double* d_px = path_x ? p : nullptr; p += path_elems;
         double* d_pz = path_x ? p : nullptr;
@@ -819,13 +840,25 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         HIP_TRY(hipMemcpyAsync(d_bmag, bmag, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_alt, alt, alt_elems * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_f, freq_hz, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_f, freq_hz, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_e, elevation_deg, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
         if (profile_index)
-            HIP_TRY(hipMemcpyAsync(d_i, profile_index, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
-        a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.freq_hz = d_f; a.elev_deg = d_e;
-        a.prof_idx = profile_index ? d_i : nullptr;
+            HIP_TRY(hipMemcpyAsync(d_i, profile_index, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
+        if (grouped)
+            HIP_TRY(hipMemcpyAsync(d_g, ray_group, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.elev_deg = d_e;
+        d_keyf = d_f;
+        d_keyp = profile_index ? d_i : nullptr;
+        d_group = grouped ? d_g : nullptr;
         a.out = d_out; a.path_x = d_px; a.path_z = d_pz;
+    }
+    if (grouped) {
+        a.ray_group = d_group; a.group_freq = d_keyf; a.group_prof = d_keyp; a.n_groups = n_groups;
+        int rc3 = ensure(c, c->levels, level_bytes);
+        if (rc3 != PRHF_OK) return rc3;
+        a.levels = static_cast<double*>(c->levels.p);
+    } else {
+        a.freq_hz = d_keyf; a.prof_idx = d_keyp;
     }
     {
         int rc2 = ensure(c, c->partial, (size_t)n_prof * 16);      // per-profile scalars (the operator's chunk scratch is free here)
@@ -870,6 +903,22 @@ int prhf_snell_spherical_f64(prhf_ctx* c, const double* freq_hz, const double* e
     const SnellGeometry geo{1, earth_radius_km, dz_target_km, apex_boost, max_substeps};
     return snell_run(c, geo, freq_hz, elevation_deg, profile_index, n_rays, den, bmag, bpsi, alt, n_prof, n_alt,
                      alt_stride_elems, mode, out, path_x, path_z, path_stride, flags);
+}
+
+int prhf_snell_fan_f64(prhf_ctx* c, int32_t geometry, const double* group_freq_hz, const int64_t* group_profile_index,
+                       int64_t n_groups, const int64_t* ray_group, const double* elevation_deg, int64_t n_rays,
+                       const double* den, const double* bmag, const double* bpsi, const double* alt, int64_t n_prof,
+                       int64_t n_alt, int64_t alt_stride_elems, int32_t mode, double earth_radius_km,
+                       double dz_target_km, double apex_boost, int32_t max_substeps, double* out, double* path_x,
+                       double* path_z, int64_t path_stride, uint32_t flags) {
+    if (geometry != 0 && geometry != 1) return fail(PRHF_EINVAL, "geometry is 0 (flat Earth) or 1 (spherical Earth)");
+    if (!ray_group) return fail(PRHF_EINVAL, "null array pointer");
+    if (geometry == 1 && (!(earth_radius_km > 0.0) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) || max_substeps < 1))
+        return fail(PRHF_EINVAL, "bad spherical tracer controls");
+    const SnellGeometry geo = geometry == 0 ? SnellGeometry{0, 6371.0, 1.0, 200.0, 400}
+                                            : SnellGeometry{1, earth_radius_km, dz_target_km, apex_boost, max_substeps};
+    return snell_run(c, geo, group_freq_hz, elevation_deg, group_profile_index, n_rays, den, bmag, bpsi, alt, n_prof, n_alt,
+                     alt_stride_elems, mode, out, path_x, path_z, path_stride, flags, ray_group, n_groups);
 }
 
 int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups_per_cu) {

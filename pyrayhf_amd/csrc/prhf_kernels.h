@@ -133,6 +133,13 @@ struct SnellArgs {
     const double* freq_hz;       // (n_rays)
     const double* elev_deg;      // (n_rays)
     const long long* prof_idx;   // (n_rays) or null: every ray uses profile 0
+    // Grouped launch (prhf_snell_fan_f64): rays that share (profile, frequency) read their levels from a table
+    // computed once per group instead of evaluating the Appleton-Hartree index level by level themselves.
+    const long long* ray_group;  // (n_rays) group of each ray, or null: ungrouped (freq_hz / prof_idx per ray)
+    const double* group_freq;    // (n_groups) [Hz]
+    const long long* group_prof; // (n_groups) or null: profile 0
+    long long n_groups;
+    double* levels;              // (n_groups, n_alt + 1, 2) mu and mu' of every level (ground level first when inserted)
     double* prof_info;           // (n_prof, 2) scratch: max|B| and "has a negative density", filled by launch_snell
     long long n_prof;
     double* out;                 // (n_rays, PRHF_SNELL_OUTPUTS)
@@ -147,7 +154,7 @@ struct SnellArgs {
     double apex_boost;
     int max_substeps;
 };
-hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);
+hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
 
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,

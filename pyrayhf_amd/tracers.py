@@ -3,7 +3,10 @@
 ``trace_ray_cartesian_snells`` and ``trace_ray_spherical_snells`` keep the reference's signatures
 and result dictionaries (reference ``PyRayHF/library.py:1096-1268``, ``:1460-1713``);
 ``trace_rays_cartesian_snells`` / ``trace_rays_spherical_snells`` trace a batch of
-(frequency, elevation[, profile]) rays in one launch, one wavefront per ray.
+(frequency, elevation[, profile]) rays in one launch, one wavefront per ray;
+``trace_fan_cartesian_snells`` / ``trace_fan_spherical_snells`` trace every elevation of a fan for every
+frequency (and profile): the refractive-index levels, which depend on the profile and the frequency only, are
+computed once per (profile, frequency) and shared by the fan's rays.
 """
 
 from __future__ import annotations
@@ -14,7 +17,7 @@ from . import _native
 from .library import _as_rows, constants
 
 __all__ = ["trace_ray_cartesian_snells", "trace_rays_cartesian_snells", "trace_ray_spherical_snells",
-           "trace_rays_spherical_snells"]
+           "trace_rays_spherical_snells", "trace_fan_cartesian_snells", "trace_fan_spherical_snells"]
 
 _KEYS = ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km", "x_turn_km",
          "z_turn_km", "n_path")
@@ -57,6 +60,65 @@ def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, p
     if return_paths:
         res["x"], res["z"] = px, pz
     return res
+
+
+def _trace_fan(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, controls):
+    if mode not in ("O", "X"):
+        raise ValueError("Mode must be O or X")
+    f = np.ascontiguousarray(np.atleast_1d(np.asarray(f0_Hz, dtype=np.float64)))
+    e = np.ascontiguousarray(np.atleast_1d(np.asarray(elevation_deg, dtype=np.float64)))
+    if f.ndim != 1 or e.ndim != 1:
+        raise ValueError("f0_Hz and elevation_deg must be 1-D (frequencies, elevations of the fan)")
+    single = np.ndim(Ne) == 1
+    d2, b2, p2 = (np.atleast_2d(_as_rows(n, x)) for n, x in (("Ne", Ne), ("Babs", Babs), ("bpsi", bpsi)))
+    if not (d2.shape == b2.shape == p2.shape):
+        raise ValueError("Ne, Babs and bpsi must have the same shape")
+    n_prof, n_alt = d2.shape
+    a = _as_rows("alt_km", alt_km)
+    if a.shape[-1] != n_alt or (a.ndim == 2 and a.shape[0] != n_prof):
+        raise ValueError("alt_km must have one value per level")
+    # groups: (profile, frequency) in C order; rays: (profile, frequency, elevation) in C order
+    group_f = np.ascontiguousarray(np.tile(f, n_prof))
+    group_p = np.ascontiguousarray(np.repeat(np.arange(n_prof, dtype=np.int64), f.size))
+    n_groups = group_f.size
+    ray_group = np.ascontiguousarray(np.repeat(np.arange(n_groups, dtype=np.int64), e.size))
+    ray_e = np.ascontiguousarray(np.tile(e, n_groups))
+    n_rays = ray_e.size
+    out = np.empty((n_rays, 8), dtype=np.float64)
+    stride = 2 * n_alt + 1
+    px = np.empty((n_rays, stride), dtype=np.float64) if return_paths else None
+    pz = np.empty((n_rays, stride), dtype=np.float64) if return_paths else None
+    r_e, dz_t, boost, nsub = controls if spherical else (6371.0, 1.0, 200.0, 400)
+    ctx = _native.host_context(device)
+    rc = ctx.snell_fan(1 if spherical else 0, group_f.ctypes.data, group_p.ctypes.data, n_groups, ray_group.ctypes.data,
+                       ray_e.ctypes.data, n_rays, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof,
+                       n_alt, n_alt if a.ndim == 2 else 0, _native.MODE_O if mode == "O" else _native.MODE_X,
+                       r_e, dz_t, boost, nsub, out.ctypes.data, px.ctypes.data if return_paths else None,
+                       pz.ctypes.data if return_paths else None, stride, 0)
+    _native.raise_for(rc)
+    shape = (f.size, e.size) if single else (n_prof, f.size, e.size)
+    res = {k: out[:, i].reshape(shape).copy() for i, k in enumerate(_KEYS)}
+    res["n_path"] = res["n_path"].astype(np.int64)
+    if return_paths:
+        res["x"], res["z"] = px.reshape(shape + (stride,)), pz.reshape(shape + (stride,))
+    return res
+
+
+def trace_fan_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, return_paths=False, device=None):
+    """Every elevation of ``elevation_deg`` ``(E,)`` for every frequency of ``f0_Hz`` ``(F,)`` (and every profile
+    when ``Ne, Babs, bpsi`` are ``(P, N_alt)``), flat Earth.  Returns the dict of ``trace_rays_cartesian_snells``
+    with arrays of shape ``(F, E)`` (or ``(P, F, E)``), bit for bit the values the per-ray call gives for the
+    same rays; the level-by-level refractive index is evaluated once per (profile, frequency) instead of once
+    per ray (``prhf_snell_fan_f64``)."""
+    return _trace_fan(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, None)
+
+
+def trace_fan_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
+                               apex_boost=200.0, max_substeps=400, R_E=None, return_paths=False, device=None):
+    """The same over a spherical Earth, with the reference's apex-refinement controls (library.py:1470-1473)."""
+    r_e = constants()[2] if R_E is None else float(R_E)
+    return _trace_fan(True, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device,
+                      (r_e, dz_target_km, apex_boost, max_substeps))
 
 
 def _single(r, apex_keys):

@@ -315,3 +315,49 @@ def test_flag_validation_of_the_grid_stable_bit():
     rc = ctx.vfo_batch(one.ctypes.data, 1, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data,
                        1, 4, 4, 0, one.ctypes.data, 4, 0, out.ctypes.data, _native.FLAG_GRID_STABLE)
     assert rc == _native.EINVAL and "device pointers" in _native.last_error()
+
+
+@pytest.mark.parametrize("slope_deg_per_km,kind", [(0.0005, "linear"), (0.002, "quadratic"), (0.01, "cubic"),
+                                                    (0.05, "sin per point")])
+def test_every_degree_of_the_sin2_polynomial(lib, slope_deg_per_km, kind):
+    """The main loop carries sin^2(psi) inside a segment as a linear, quadratic or cubic polynomial depending on
+    how fast the field angle turns (stage_profile), and falls back to sin() per point beyond 3e-4 rad per level:
+    each variant - with the top-segment phase at n_points = 20000 and without it at 500 - against the reference
+    order (X mode: 1e-9) and the plain-C oracle."""
+    from oracle import vfo_c
+    g = load_golden("g5_chapman64.npz")
+    alt = g["alt"]
+    bpsi = 20.0 + np.arange(64)[:, None] + slope_deg_per_km * (alt[None, :] - 80.0)
+    freq = g["freq"][::2]
+    for n in (500, 20000):
+        rows = slice(0, 64) if n == 500 else slice(0, 24)      # both: >= 4096 pairs or a long grid -> main loop
+        fast = lib.vertical_forward_operator(freq, g["den"][rows], g["bmag"][rows], bpsi[rows], alt, "X", n)
+        slow = lib.vertical_forward_operator(freq, g["den"][rows], g["bmag"][rows], bpsi[rows], alt, "X", n,
+                                             math=lib.MATH_FAITHFUL)
+        worst = assert_x_mode(fast, slow, tol=1e-9)
+        if vfo_c.available() and n == 500:
+            assert_x_mode(fast, vfo_c.virtual_heights_batch(freq, g["den"][rows], g["bmag"][rows], bpsi[rows], alt, "X", n),
+                          tol=1e-9)
+        print(f"sin^2 {kind} n={n}: fast vs reference order {worst:.2e}")
+        vo = lib.vertical_forward_operator(freq, g["den"][rows], g["bmag"][rows], bpsi[rows], alt, "O", n)
+        vf = lib.vertical_forward_operator(freq, g["den"][rows], g["bmag"][rows], bpsi[rows], alt, "O", n,
+                                           math=lib.MATH_FAITHFUL)
+        assert_masks(vo, vf)
+        err, ok = rel_err(vo, vf)
+        assert err.max() <= 2e-8, (kind, n, err.max())         # default O-mode arithmetic vs reference order everywhere
+
+
+def test_more_frequencies_than_the_candidate_list_holds(lib):
+    """The per-profile candidate list holds 1024 frequencies; a longer sweep takes the path without it (every
+    frequency is a work item, the escape test runs per pair) and must give the same values."""
+    g = load_golden("g5_chapman64.npz")
+    freq = np.linspace(0.3, 17.0, 1100)
+    long_ = lib.vertical_forward_operator(freq, g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
+    head = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
+    assert np.array_equal(long_[:, :1000], head, equal_nan=True)
+    lo = lib.vertical_forward_operator(freq, g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "O", 200)
+    ho = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "O", 200)
+    # O mode, n_points = 200: four frequencies share a tail iteration, but the tail is evaluated point by point in
+    # the reference's order - grouping does not change a value
+    assert np.array_equal(lo[:, :1000], ho, equal_nan=True)
+    assert 0.3 < np.isfinite(long_).mean() < 0.8

@@ -127,3 +127,34 @@ def test_spherical_single_ray_and_flat_limit():
     esc = tracers.trace_ray_spherical_snells(30e6, 80.0, alt_km, Ne, B, psi, "O")
     assert set(esc) == {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km"}
     assert all(np.isnan(v) for v in esc.values())
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_fan_shares_the_levels_and_changes_nothing(spherical):
+    """prhf_snell_fan_f64: the refractive-index levels once per (profile, frequency), read by every elevation of the
+    fan.  Same arithmetic, so bit for bit the per-ray call's outputs - scalars and paths - and, through them, the
+    reference's rays (fixtures G8 / G9 are fans: 8 or 5 frequencies x 7 or 6 elevations per mode)."""
+    from pyrayhf_amd import tracers
+    g = load_golden("g8_snell.npz")
+    for name in ("gauss", "day"):
+        prof = [g[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
+        freqs = np.array([2.0, 3.5, 5.0, 7.0, 9.0, 10.0, 12.5, 16.0]) * 1e6
+        elevs = np.array([5.0, 20.0, 45.0, 70.0, 85.0, 89.9, 90.0])
+        for mode in "OX":
+            fan_fn = tracers.trace_fan_spherical_snells if spherical else tracers.trace_fan_cartesian_snells
+            ray_fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+            fan = fan_fn(freqs, elevs, *prof, mode, return_paths=True)
+            ff, ee = np.meshgrid(freqs, elevs, indexing="ij")
+            rays = ray_fn(ff.ravel(), ee.ravel(), *prof, mode, return_paths=True)
+            for key in ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km", "x_turn_km",
+                        "z_turn_km", "n_path", "x", "z"):
+                assert fan[key].shape[:2] == (freqs.size, elevs.size)
+                assert np.array_equal(fan[key].reshape(rays[key].shape), rays[key], equal_nan=True), (name, mode, key)
+            assert np.isfinite(fan["group_path_km"]).any() and np.isnan(fan["group_path_km"]).any()
+    # several profiles: (P, F, E)
+    two = [np.stack([g["gauss_den"], 0.5 * g["gauss_den"]]), np.stack([g["gauss_bmag"]] * 2), np.stack([g["gauss_bpsi"]] * 2)]
+    fan = tracers.trace_fan_cartesian_snells(np.array([5e6, 7e6]), np.array([20.0, 60.0, 80.0]), g["gauss_alt"], *two, "O")
+    assert fan["group_path_km"].shape == (2, 2, 3)
+    one = tracers.trace_fan_cartesian_snells(np.array([5e6, 7e6]), np.array([20.0, 60.0, 80.0]), g["gauss_alt"],
+                                             two[0][1], two[1][1], two[2][1], "O")
+    assert np.array_equal(fan["group_path_km"][1], one["group_path_km"], equal_nan=True)
