@@ -602,17 +602,17 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // D > 0 (X < 1 in O mode, X + Y < 1 in X mode, at every level and therefore between the levels: the three
 // interpolants are linear) - no sign transfer, no validity compare - and written around a = 1 - X:
 //   G = s beta - h,  D = a + G,  N = D - X a = G + a^2,  D - X = D - cX den,  (1 + X)/2 = k
-// 32 instructions from (den, b, S2): 15 FMA, 14 MUL, 1 ADD, 2 v_rsq_f64 (the version through X needed 34).
+// 30 instructions from (den, Y^2, S2) - with Y^2 = cY2 b^2 (two more) 32: 15 FMA, 14 MUL, 1 ADD, 2 v_rsq_f64
+// (the version through X needed 34).
 // khcX = 0.5 s cX (s = +1 O, -1 X) rides in a scalar register like cX and cY2.
 template <int MODE>
-__device__ __forceinline__ double group_index_lean(double den, double b, double S2, double cX, double khcX,
-                                                   double cY2, double* a_out) {
+__device__ __forceinline__ double group_index_lean(double den, double Y2, double S2, double cX, double khcX,
+                                                   double* a_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double a = __builtin_fma(-cX, den, 1.0);             // 1 - X
-    const double B2 = b * b;
-    const double YT2 = (cY2 * B2) * S2;
-    const double YL2 = __builtin_fma(cY2, B2, -YT2);           // Y^2 cos^2 psi
+    const double YT2 = Y2 * S2;
+    const double YL2 = Y2 - YT2;                               // Y^2 cos^2 psi
     const double t = a * YL2;
     const double h = 0.5 * YT2;
     const double alpha = __builtin_fma(h, h, t * a);
@@ -698,7 +698,7 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     const double S2 = POLY == 1 ? ua.x + x * ua.y
                     : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
     double a;
-    const double mup = group_index_lean<MODE>(den, b, S2, cX, khcX, cY2, &a);
+    const double mup = group_index_lean<MODE>(den, cY2 * (b * b), S2, cX, khcX, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -706,13 +706,14 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
 // The top segment of a pair in m: about half of a long grid's points lie between the last level below the
 // reflection height and the reflection height itself (the stretched grid is dense there).  For those points the
 // node is the same for every lane and every trip, so the three interpolants become polynomials in m with
-// wave-uniform coefficients - no segment index, no LDS read, no abscissa: 36 instructions per point instead of 40.
+// wave-uniform coefficients - no segment index, no LDS read, no abscissa, Y straight from m: 35 instructions
+// per point instead of 40 (34 against 39 with the linear sin^2 psi).
 struct TopSegment {
     double d0, d1;          // den  = d0 + d1 m
-    double b0, b1;          // |B|  = b0 + b1 m
+    double b0, b1;          // Y = g_p |B| / f = b0 + b1 m
     double q0, q1, q2, q3;  // sin^2 psi = q0 + m (q1 + m (q2 + m q3))
 };
-__device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, double span) {
+__device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, double span, double cY) {
 #pragma clang fp contract(fast)
     typedef __attribute__((address_space(3))) const double* LdsDouble;
     const LdsDouble nd = (LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
@@ -721,7 +722,7 @@ __device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, doubl
     const double den = nd[2], sden = nd[3], b = nd[4], sb = nd[5], u0 = nd[6], u1 = nd[7], u2 = nd[8], u3 = nd[9];
     TopSegment t;
     t.d0 = den + sden * o;  t.d1 = sden * s;
-    t.b0 = b + sb * o;      t.b1 = sb * s;
+    t.b0 = cY * (b + sb * o);  t.b1 = cY * (sb * s);
     t.q0 = u0 + o * (u1 + o * (u2 + o * u3));
     t.q1 = s * (u1 + o * (2.0 * u2 + 3.0 * o * u3));
     t.q2 = (s * s) * (u2 + 3.0 * o * u3);
@@ -734,11 +735,12 @@ __device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, 
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     const double den = t.d1 * m0 + t.d0;
-    const double b = t.b1 * m0 + t.b0;
+    const double Y = t.b1 * m0 + t.b0;
     const double S2 = POLY == 1 ? t.q0 + m0 * t.q1
                     : (POLY == 2 ? t.q0 + m0 * (t.q1 + m0 * t.q2) : t.q0 + m0 * (t.q1 + m0 * (t.q2 + m0 * t.q3)));
     double a;
-    const double mup = group_index_lean<MODE>(den, b, S2, cX, khcX, cY2, &a);
+    const double mup = group_index_lean<MODE>(den, Y * Y, S2, cX, khcX, &a);
+    (void)cY2;
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -830,7 +832,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             const int aligned = first + ((lo - first + 63) & ~63);
             if (aligned + 128 <= whole_end) {          // worth a second loop
                 split = aligned;
-                top = top_segment(nodes_v, j_top, span);
+                top = top_segment(nodes_v, j_top, span, uniform(sqrt(cY2)));      // Y = g_p |B| / f: cY = g_p / f
                 top_phase = true;
             }
         }
@@ -846,10 +848,17 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             g0 = grid_at(first + 128);
             accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
         } else {
+            unsigned long long viol2 = 0;
             const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol, nodes_v, hint_v);
-            if (viol) break;                           // neither half of this trip counts
+            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol2, nodes_v, hint_v);
+            if (viol) break;                           // the first half fails the check: nothing of this trip counts
+            if (viol2) {                               // only the second half does: keep the first
+                accm = a1;
+                first += 64;
+                viol = viol2;
+                break;
+            }
             accm = a2;
             g0 = g2;
         }
@@ -870,10 +879,17 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
                 g0 = grid_at(first + 128);
                 accm = lean_step_top<MODE, false, POLY>(g1, top, cX, khcX, cY2, accm, wc, viol);
             } else {
+                unsigned long long viol2 = 0;
                 const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
                 const double2 g2 = grid_at(first + 128);
-                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, cY2, a1, wc, viol);
+                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, cY2, a1, wc, viol2);
                 if (viol) break;
+                if (viol2) {
+                    accm = a1;
+                    first += 64;
+                    viol = viol2;
+                    break;
+                }
                 accm = a2;
                 g0 = g2;
             }

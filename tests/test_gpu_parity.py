@@ -270,7 +270,9 @@ def test_torch_async_launch_is_ordered_on_the_callers_stream(lib):
         assert np.array_equal(doubled.cpu().numpy(), want * 2.0, equal_nan=True)
     # back to host inputs on the same context afterwards
     again = lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"][:2], g["bpsi"][:2], g["alt"], "X", 20000)
-    assert_x_mode(again, want[:2], tol=1e-12)         # two profiles are chunked: another summation order
+    # two profiles are cut into chunks: another summation order, and other grid points fall into the main loop's
+    # top-segment phase (whose interpolants are the same polynomials rounded differently): agreement to ~1e-12
+    assert_x_mode(again, want[:2], tol=1e-11)
 
 
 def test_mixed_worklist_on_device_tensors(lib):
