@@ -142,3 +142,15 @@ def test_tall_profiles_one_workgroup_per_cu(n_alt):
         alt2 = np.linspace(80.0, 700.0, 1401)
         with pytest.raises(ValueError):
             library.vertical_forward_operator(freq, np.ones((1, 1401)), np.ones((1, 1401)), np.ones((1, 1401)), alt2, "X", 200)
+
+
+@pytest.mark.parametrize("seed", [5000, 5001, 5002, 5003, 5004, 5005])
+def test_random_batches_on_the_long_launch_paths(seed):
+    """Batches of >= 4096 pairs (candidate list, running-maximum search, four-frequency items with shared tails,
+    main loop with partial iterations and the top-segment phase, hint-table variant): tests/devtools/
+    random_sweep_batches.py, a few seeds of it."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devtools"))
+    from random_sweep_batches import check
+    checked, bad = check(seed)
+    assert bad == 0
