@@ -35,7 +35,8 @@ extern "C" {
 
 /* return codes */
 #define PRHF_OK        0
-#define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination, bad segment or index */
+#define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination, bad segment or index,
+                            * a host-buffer frequency that is not positive and finite */
 #define PRHF_ENEGDEN  -2   /* a density below the peak is negative (reference library.py:93-94 raises ValueError) */
 #define PRHF_EPEAK0   -3   /* density peak at index 0: empty bottomside (the reference raises IndexError) */
 #define PRHF_EHIP     -4   /* HIP runtime failure; message carries hipGetErrorString */

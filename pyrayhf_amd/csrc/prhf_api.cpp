@@ -199,6 +199,12 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
         return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
+    // Host buffers: a sounder frequency must be a positive finite number (the reference divides by it and returns
+    // NaN or garbage silently for 0, negative and NaN frequencies; device-resident frequencies are the caller's).
+    if (!dev)
+        for (int64_t i = 0; i < n_freq; ++i)
+            if (!(freq[i] > 0.0) || !std::isfinite(freq[i]))
+                return fail(PRHF_EINVAL, "freq[%lld] must be a positive finite number (MHz)", (long long)i);
 
     ENTER_DEVICE(c->device);
 

@@ -122,7 +122,7 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     double s, c;
     // sin, cos, YT**4 and YT**3 rounded the way the reference's libm / NumPy pow round them (prhf_crmath.h):
     // near reflection D cancels to 1e-9 of its terms and these roundings decide the last grid points
-    if (__builtin_fabs(r) < 1.0e6) prhf_cr::sincos(r, &s, &c);
+    if (__builtin_fabs(r) < 1.0e6) prhf_cr::sincos_table(r, &s, &c);
     else sincos(r, &s, &c);
     const double YT = Y * s;                                   // :210
     const double YL = Y * c;                                   // :211

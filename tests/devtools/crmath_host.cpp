@@ -5,6 +5,9 @@ extern "C" {
 void cr_sincos(const double* r, long n, double* s, double* c) {
     for (long i = 0; i < n; ++i) prhf_cr::sincos(r[i], &s[i], &c[i]);
 }
+void cr_sincos_table(const double* r, long n, double* s, double* c) {
+    for (long i = 0; i < n; ++i) prhf_cr::sincos_table(r[i], &s[i], &c[i]);
+}
 void cr_pow34(const double* x, long n, double* p3, double* p4) {
     for (long i = 0; i < n; ++i) {
         p3[i] = prhf_cr::pow3(x[i]);

@@ -194,6 +194,9 @@ def test_error_behaviour(lib):
         lib.vertical_forward_operator(g["freq"], g["den"][::-1].copy(), g["bmag"], g["bpsi"], g["alt"], "O", 10)
     with pytest.raises(ValueError):
         lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    for bad_f in (0.0, -3.0, np.nan, np.inf):              # stricter than the reference, which returns NaN / garbage
+        with pytest.raises(ValueError, match="positive finite"):
+            lib.vertical_forward_operator(np.array([2.0, bad_f]), g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 10)
     # the context stays usable after a data error
     vh = lib.vertical_forward_operator(*args, "O", 50)
     assert np.isfinite(vh[0])
