@@ -425,7 +425,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             // sin^2(psi_j + r dz) = S + sin(2 psi_j) r dz + cos(2 psi_j) (r dz)^2 - (2/3) sin(2 psi_j) (r dz)^3 + O(4)
             const double r = spsi * kDegToRad;
             double sp, cp;
-            sincos(p * kDegToRad, &sp, &cp);
+            prhf_cr::sincos_table(p * kDegToRad, &sp, &cp);      // (100 vector instructions; the device library's: 155)
             const double s2p = 2.0 * (sp * cp), c2p = (cp - sp) * (cp + sp);
             nd.u0 = sp * sp;
             nd.u1 = s2p * r;
