@@ -1,21 +1,24 @@
 // prhf_kernels.hip - fused vertical-ionogram forward operator for gfx950 (MI355X, CDNA4).
 //
-// One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its
-// stretched grid when few pairs are submitted.  A workgroup shares one profile: its
-// bottomside columns are staged once into LDS as 80-byte nodes, so that every grid point
-// costs one LDS round trip (4 ds_read_b128 + 1 ds_read_b64) and no HBM traffic.  Per pair:
-//   S3-S6  reflection height: lanes stride over the levels, first level with X (or X+Y) > 1
-//          by ballot, running maximum below it by a wave max-reduce, np.interp semantics;
-//   S7-S10 lanes stride over the n_points stretched altitudes: locate the segment (closed
-//          form on uniform grids, LDS hint table otherwise), interpolate den/|B|/psi
-//          linearly, Appleton-Hartree mu and mu';
+// One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its stretched grid when
+// few pairs are submitted, or four pairs on short O-mode grids.  A workgroup shares one profile: its bottomside
+// columns are staged once into LDS as 96-byte nodes (stage_profile), so that every grid point costs at most one
+// LDS round trip and no HBM traffic.  Per pair:
+//   S3-S6  reflection height (reflection_height): X mode - lanes stride over the levels, first level with
+//          X + Y > 1 by ballot, running maximum below it by a wave max-reduce; O mode - a 64-ary search in the
+//          profile's running maximum of f_N^2 (prefix_max_in_place); np.interp semantics either way;
+//   S7-S10 the n_points stretched altitudes: segment (closed form on uniform grids, LDS hint table otherwise;
+//          none at all in the top segment, whose node is held in registers), linear interpolation of
+//          den/|B|/psi, Appleton-Hartree mu and mu' (lean_loop: the main loop; integrate_chunk: the generic loop);
 //   S11    left-rectangle sum of mu'*dh with NaNs skipped, wave sum-reduce, 0 -> NaN, + min(alt).
+// Frequencies that escape for certain never become work items (list_candidates).
 // Stage names S0-S11 are SURVEY.md section 2.1; reference line numbers are PyRayHF/library.py.
 //
 // Two arithmetic tiers (DESIGN.md "Arithmetic tiers"):
-//   TIER 0 "faithful": the reference's operation order, IEEE divide and sqrt, no contraction;
-//   TIER 1 "fast":     algebraically reduced mu' (38 FP64 operations + 2 v_rsq_f64 per point on
-//                      the main loop), sin^2(psi) by a per-segment cubic, FMA contraction.
+//   TIER 0: the reference's operation order, IEEE divide and sqrt, no contraction, sin/cos/pow rounded like a
+//           correctly rounding libm (prhf_crmath.h) - everywhere, or (default for O mode) where 1 - X <= 1e-5;
+//   TIER 1: algebraically reduced mu' (group_index_lean: 30 operations from (den, Y^2, sin^2 psi), 2 v_rsq_f64),
+//           sin^2(psi) by a per-segment polynomial, FMA contraction - the default for X mode.
 //
 // No MFMA: the work is elementwise float64 transcendental + reduction ("Roofline").
 
