@@ -386,10 +386,13 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             }
         }
         a.pairs = static_cast<const double*>(c->pairs.p);
-        // per-frequency scalars: long launches read them from a table instead of dividing once per pair
-        if ((rc = ensure(c, c->ftab, (size_t)n_freq * 64)) != PRHF_OK) return rc;
-        HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), c->stream));
-        a.ftab = static_cast<const double*>(c->ftab.p);
+        // per-frequency scalars: long launches read them from a table instead of dividing once per pair (a short
+        // launch - one profile - is latency bound: it does without the extra kernel)
+        if (n_prof * n_freq >= 4096) {
+            if ((rc = ensure(c, c->ftab, (size_t)n_freq * 64)) != PRHF_OK) return rc;
+            HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), c->stream));
+            a.ftab = static_cast<const double*>(c->ftab.p);
+        }
     }
 #ifdef PRHF_TRACE
     // diagnostics build (tools/wave_trace.py): per-wave wall-clock stamps of this launch, dumped to $PRHF_TRACE_FILE

@@ -982,7 +982,9 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
                                                                  span, a0, kj, cX, cY2, well_conditioned)
 #define PRHF_LEAN_POLY(H, T) (poly == 1 ? PRHF_LEAN(1, H, T) : (poly == 2 ? PRHF_LEAN(2, H, T) : PRHF_LEAN(3, H, T)))
             if (by_hint) r = PRHF_LEAN_POLY(true, false);
-            else if (lean_end - first >= 1024) r = PRHF_LEAN_POLY(false, true);
+            // (a chunk of a pair keeps to the indexed steps: the search for the top segment's first point costs
+            // three dependent loads, which a latency-bound chunked launch cannot hide and every chunk would repeat)
+            else if (lean_end - first >= 1024 && i0 == 0 && to_grid_end) r = PRHF_LEAN_POLY(false, true);
             else r = PRHF_LEAN_POLY(false, false);
 #undef PRHF_LEAN_POLY
 #undef PRHF_LEAN
