@@ -1546,47 +1546,46 @@ __global__ void vfo_finalize_kernel(const KArgs a, int s) {
 }
 
 // Standalone Appleton-Hartree indices on flat arrays (find_mu_mup, library.py:161-256).
-// `unmag` is decided by the caller over the whole array, as the reference does (:201).
+// The reference switches to the isotropic formulas when nanmax|Y| < 1e-12 over the WHOLE array (:201).  That is
+// decided here in the same pass: the magnetised formulas are evaluated while max|Y| is collected (`track`: two
+// words that start at 0 - [0] max |Y| ignoring NaN, as a bit pattern, which orders like the double for non-negative
+// values; [1] != 0 when any element was not NaN), and only if the array turns out to be isotropic - it almost
+// never is - the launcher runs the pass again with `unmag` set.  (A separate pre-pass read Y a second time: 48
+// instead of 40 bytes moved per element of an HBM-bound op.)
 template <int TIER>
 __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __restrict__ Y,
                               const double* __restrict__ psi, long long n, int mode, int unmag,
-                              double* __restrict__ mu_out, double* __restrict__ mup_out) {
+                              double* __restrict__ mu_out, double* __restrict__ mup_out,
+                              unsigned long long* track) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    double ymax = 0.0;
+    int seen = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double mu, mup;
+        const double y = Y[i];
+        const double ay = fabs(y);
+        ymax = fmax(ymax, ay);
+        seen |= (ay == ay) ? 1 : 0;
         if (unmag) {
             index_unmagnetised(X[i], &mu, &mup);
         } else if (TIER == 0) {
-            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(X[i], Y[i], psi[i], &mu, &mup);
-            else index_faithful<PRHF_KMODE_X>(X[i], Y[i], psi[i], &mu, &mup);
+            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(X[i], y, psi[i], &mu, &mup);
+            else index_faithful<PRHF_KMODE_X>(X[i], y, psi[i], &mu, &mup);
         } else {
             const double sn = sin(psi[i] * kDegToRad);
-            const double y = Y[i];
             if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], y * y, sn * sn, &mu, &mup);
             else index_fast<PRHF_KMODE_X>(X[i], y * y, sn * sn, &mu, &mup);
         }
         mu_out[i] = mu;
         mup_out[i] = mup;
     }
-}
-
-// max |Y| ignoring NaN (np.nanmax(np.abs(Y)), library.py:201) in result[0] (bit pattern of a
-// non-negative double orders like the integer); result[1] != 0 when any element was not NaN.
-// Both words must start at 0.
-__global__ void absmax_kernel(const double* __restrict__ Y, long long n, unsigned long long* result) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    double m = 0.0;
-    int seen = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double y = fabs(Y[i]);
-        m = fmax(m, y);
-        seen |= (y == y) ? 1 : 0;
-    }
-    m = wave_max(m);
-    seen = __any(seen) ? 1 : 0;
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(result, (unsigned long long)__double_as_longlong(m));
-        if (seen) atomicOr(result + 1, 1ull);
+    if (track) {
+        ymax = wave_max(ymax);
+        seen = __any(seen) ? 1 : 0;
+        if ((threadIdx.x & 63) == 0) {             // (a few thousand waves: the two atomics per wave do not show)
+            atomicMax(track, (unsigned long long)__double_as_longlong(ymax));
+            if (seen) atomicOr(track + 1, 1ull);
+        }
     }
 }
 
@@ -1620,20 +1619,24 @@ hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, lo
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipError_t e = hipMemsetAsync(absmax_scratch, 0, 2 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, Y, n, absmax_scratch);
-    e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    double ymax;
-    __builtin_memcpy(&ymax, absmax_host, sizeof ymax);
-    // all-NaN Y: np.nanmax gives NaN and the comparison is false -> magnetised formulas
-    const int unmag = (absmax_host[1] != 0 && ymax < kUnmagTol) ? 1 : 0;
-    if (tier == 0)
-        hipLaunchKernelGGL(mu_mup_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup);
-    else
-        hipLaunchKernelGGL(mu_mup_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup);
-    return hipGetLastError();
+    for (int unmag = 0; unmag < 2; ++unmag) {
+        unsigned long long* track = unmag ? nullptr : absmax_scratch;
+        if (tier == 0)
+            hipLaunchKernelGGL(mu_mup_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup, track);
+        else
+            hipLaunchKernelGGL(mu_mup_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, n, mode, unmag, mu, mup, track);
+        e = hipGetLastError();
+        if (e != hipSuccess || unmag) return e;
+        e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        double ymax;
+        __builtin_memcpy(&ymax, absmax_host, sizeof ymax);
+        // all-NaN Y: np.nanmax gives NaN and the comparison is false -> magnetised formulas (already written)
+        if (!(absmax_host[1] != 0 && ymax < kUnmagTol)) return hipSuccess;
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1643,15 +1646,20 @@ hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, lo
 template <int TIER>
 __global__ void find_vh_kernel(const double* __restrict__ X, const double* __restrict__ Y,
                                const double* __restrict__ psi, const double* __restrict__ dh, long long n_rows,
-                               long long n_cols, double alt_min, int mode, int unmag, double* __restrict__ vh) {
+                               long long n_cols, double alt_min, int mode, int unmag, double* __restrict__ vh,
+                               unsigned long long* track) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const long long base = row * n_cols;
-    double acc = 0.0;
+    double acc = 0.0, ymax = 0.0;
+    int seen = 0;
     for (long long i = lane; i < n_cols; i += 64) {
         double mu, mup;
         const double x = X[base + i], y = Y[base + i], p = psi[base + i];
+        const double ay = fabs(y);
+        ymax = fmax(ymax, ay);                                 // the isotropic test of :201, same pass (mu_mup_kernel)
+        seen |= (ay == ay) ? 1 : 0;
         if (unmag) {
             index_unmagnetised(x, &mu, &mup);
         } else if (TIER == 0) {
@@ -1667,37 +1675,43 @@ __global__ void find_vh_kernel(const double* __restrict__ X, const double* __res
     }
     acc = wave_sum(acc);
     if (lane == 0) vh[row] = (acc != 0.0) ? acc + alt_min : qnan();     // :290-292
+    if (track) {
+        ymax = wave_max(ymax);
+        seen = __any(seen) ? 1 : 0;
+        if (lane == 0) {
+            atomicMax(track, (unsigned long long)__double_as_longlong(ymax));
+            if (seen) atomicOr(track + 1, 1ull);
+        }
+    }
 }
 
 hipError_t launch_find_vh(const double* X, const double* Y, const double* psi, const double* dh, long long n_rows,
                           long long n_cols, double alt_min, int mode, int tier,
                           unsigned long long* absmax_scratch, unsigned long long* absmax_host, double* vh,
                           hipStream_t stream) {
-    const long long n = n_rows * n_cols;
     if (n_rows <= 0) return hipSuccess;
-    int unmag = 0;
-    if (n > 0) {
-        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipError_t e = hipMemsetAsync(absmax_scratch, 0, 2 * sizeof(unsigned long long), stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, Y, n, absmax_scratch);
-        e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                           stream);
+    hipError_t e = hipMemsetAsync(absmax_scratch, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
+    for (int unmag = 0; unmag < 2; ++unmag) {
+        unsigned long long* track = unmag ? nullptr : absmax_scratch;
+        if (tier == 0)
+            hipLaunchKernelGGL(find_vh_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
+                               alt_min, mode, unmag, vh, track);
+        else
+            hipLaunchKernelGGL(find_vh_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
+                               alt_min, mode, unmag, vh, track);
+        e = hipGetLastError();
+        if (e != hipSuccess || unmag) return e;
+        e = hipMemcpyAsync(absmax_host, absmax_scratch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
         double ymax;
         __builtin_memcpy(&ymax, absmax_host, sizeof ymax);
-        unmag = (absmax_host[1] != 0 && ymax < kUnmagTol) ? 1 : 0;
+        if (!(absmax_host[1] != 0 && ymax < kUnmagTol)) return hipSuccess;      // magnetised: done (:201)
     }
-    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
-    if (tier == 0)
-        hipLaunchKernelGGL(find_vh_kernel<0>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
-                           alt_min, mode, unmag, vh);
-    else
-        hipLaunchKernelGGL(find_vh_kernel<1>, dim3(blocks), dim3(256), 0, stream, X, Y, psi, dh, n_rows, n_cols,
-                           alt_min, mode, unmag, vh);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------
