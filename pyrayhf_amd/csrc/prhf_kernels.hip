@@ -48,7 +48,7 @@ constexpr double kLinTol = 1e-10;                   // a segment's quadratic ter
 // level values, sden, sb the np.interp slopes, and the abscissa is dz = z - alt_j.
 //   reference-order arithmetic: psi [deg], spsi = d(psi)/dz [deg/km]; dz is computed as the reference does.
 //   reduced arithmetic:         dz = m*span + off in one FMA, off = alt_0 - alt_j (z = m*span + alt_0, :413).
-//                  Segment turning psi by < kPolyAngle: sin^2(psi) = u0 + dz*(u1 + dz*(u2 + dz*u3));
+//                  Segment turning psi by < kPolyAngle: 2 cos^2(psi) = u0 + dz*(u1 + dz*(u2 + dz*u3));
 //                  other segments: u0 = psi_j [rad], u1 = d(psi)/dz [rad/km], u3 = NaN (the flag).
 // Both sets are staged in both tiers: the faithful tier's default mode uses the reduced arithmetic wherever
 // 1 - X is not small.
@@ -454,6 +454,8 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             } else {
                 cubic = 1;
             }
+            // stored as 2 cos^2(psi) = 2 - 2 sin^2(psi): the main loop wants Y_L^2 first (group_index_lean)
+            nd.u0 = 2.0 - 2.0 * nd.u0; nd.u1 = -2.0 * nd.u1; nd.u2 = -2.0 * nd.u2; nd.u3 = -2.0 * nd.u3;
         } else {                                   // this segment turns the field too far for the cubic
             nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
             trig = 1;
@@ -589,7 +591,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
             double S2;
             if (poly_angle || nd.u3 == nd.u3) {        // per segment; poly_angle: true for the whole profile
-                S2 = nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3));
+                S2 = 1.0 - 0.5 * (nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3)));    // the nodes hold 2 cos^2
             } else {
                 const double sn = sin(nd.u0 + nd.u1 * dz);
                 S2 = sn * sn;
@@ -605,19 +607,21 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // D > 0 (X < 1 in O mode, X + Y < 1 in X mode, at every level and therefore between the levels: the three
 // interpolants are linear) - no sign transfer, no validity compare - and written around a = 1 - X:
 //   G = s beta - h,  D = a + G,  N = D - X a = G + a^2,  D - X = D - cX den,  (1 + X)/2 = k
-// 30 instructions from (den, Y^2, S2) - with Y^2 = cY2 b^2 (two more) 32: 15 FMA, 14 MUL, 1 ADD, 2 v_rsq_f64
-// (the version through X needed 34).
+// The angle enters as C2 = 2 cos^2 psi and the field as hY2 = Y^2 / 2: Y_L^2 = hY2 C2 and h = Y_T^2 / 2 =
+// hY2 - Y_L^2 / 2 are then one product and one FMA (through sin^2 psi: Y_T^2, Y_L^2 = Y^2 - Y_T^2, h - three).
+// The difference costs h an absolute error of 1e-16 Y^2 where psi is small - and there h itself no longer matters.
+// 29 instructions from (den, Y^2/2, C2) - with Y^2/2 = (cY2/2) b^2 (two more) 31: 16 FMA, 12 MUL, 1 ADD,
+// 2 v_rsq_f64 (the version through X needed 34).
 // khcX = 0.5 s cX (s = +1 O, -1 X) rides in a scalar register like cX and cY2.
 template <int MODE>
-__device__ __forceinline__ double group_index_lean(double den, double Y2, double S2, double cX, double khcX,
+__device__ __forceinline__ double group_index_lean(double den, double hY2, double C2, double cX, double khcX,
                                                    double* a_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double a = __builtin_fma(-cX, den, 1.0);             // 1 - X
-    const double YT2 = Y2 * S2;
-    const double YL2 = Y2 - YT2;                               // Y^2 cos^2 psi
+    const double YL2 = hY2 * C2;                               // Y^2 cos^2 psi  (hY2 = Y^2 / 2, C2 = 2 cos^2 psi)
+    const double h = __builtin_fma(-0.5, YL2, hY2);            // Y^2 sin^2 psi / 2
     const double t = a * YL2;
-    const double h = 0.5 * YT2;
     const double alpha = __builtin_fma(h, h, t * a);
     const double rbeta = rsqrt_tier<MODE>(alpha);
     const double G = __builtin_fma(sgn * alpha, rbeta, -h);    // s beta - h
@@ -649,7 +653,7 @@ __device__ __forceinline__ double group_index_lean(double den, double Y2, double
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
 template <int MODE, bool CHECK, int POLY, bool HINT>
 __device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX, double khcX,
-                                            double cY2, double acc, double wc, unsigned long long& viol,
+                                            double hcY2, double acc, double wc, unsigned long long& viol,
                                             unsigned nodes_v, unsigned hint_v) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
@@ -698,10 +702,10 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     if (HINT) x = fmax(x, 0.0);                                 // the table walk guarantees alt[j] <= z: rounding only
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
-    const double S2 = POLY == 1 ? ua.x + x * ua.y
+    const double C2 = POLY == 1 ? ua.x + x * ua.y
                     : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
     double a;
-    const double mup = group_index_lean<MODE>(den, cY2 * (b * b), S2, cX, khcX, &a);
+    const double mup = group_index_lean<MODE>(den, hcY2 * (b * b), C2, cX, khcX, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -713,8 +717,8 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
 // per point instead of 40 (34 against 39 with the linear sin^2 psi).
 struct TopSegment {
     double d0, d1;          // den  = d0 + d1 m
-    double b0, b1;          // Y = g_p |B| / f = b0 + b1 m
-    double q0, q1, q2, q3;  // sin^2 psi = q0 + m (q1 + m (q2 + m q3))
+    double b0, b1;          // Y / sqrt(2) = g_p |B| / (sqrt(2) f) = b0 + b1 m
+    double q0, q1, q2, q3;  // 2 cos^2 psi = q0 + m (q1 + m (q2 + m q3))
 };
 __device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, double span, double cY) {
 #pragma clang fp contract(fast)
@@ -733,17 +737,17 @@ __device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, doubl
     return t;
 }
 template <int MODE, bool CHECK, int POLY>
-__device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, double cX, double khcX, double cY2,
+__device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, double cX, double khcX, double hcY2,
                                                 double acc, double wc, unsigned long long& viol) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
     const double den = t.d1 * m0 + t.d0;
     const double Y = t.b1 * m0 + t.b0;
-    const double S2 = POLY == 1 ? t.q0 + m0 * t.q1
+    const double C2 = POLY == 1 ? t.q0 + m0 * t.q1
                     : (POLY == 2 ? t.q0 + m0 * (t.q1 + m0 * t.q2) : t.q0 + m0 * (t.q1 + m0 * (t.q2 + m0 * t.q3)));
     double a;
-    const double mup = group_index_lean<MODE>(den, Y * Y, S2, cX, khcX, &a);
-    (void)cY2;
+    const double mup = group_index_lean<MODE>(den, Y * Y, C2, cX, khcX, &a);
+    (void)hcY2;
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -775,7 +779,8 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     // arguments arrive in VGPRs: back to SGPRs.  The node table travels as its 32-bit LDS address (a
     // generic pointer would turn every node read into a flat load).
     first = uniform(first); end = uniform(end); last_special = uniform(last_special);
-    span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX); cY2 = uniform(cY2);
+    span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX);
+    const double hcY2 = uniform(0.5 * cY2);            // Y^2 / 2 = hcY2 |B|^2 (group_index_lean)
     const double khcX = uniform((MODE == PRHF_KMODE_O ? 0.5 : -0.5) * cX);
     const double wc = CHECK ? uniform(well_conditioned) : 0.0;
     pairs = reinterpret_cast<const double2*>(
@@ -835,7 +840,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             const int aligned = first + ((lo - first + 63) & ~63);
             if (aligned + 128 <= whole_end) {          // worth a second loop
                 split = aligned;
-                top = top_segment(nodes_v, j_top, span, uniform(sqrt(cY2)));      // Y = g_p |B| / f: cY = g_p / f
+                top = top_segment(nodes_v, j_top, span, uniform(sqrt(hcY2)));     // Y / sqrt(2) = g_p |B| / (sqrt(2) f)
                 top_phase = true;
             }
         }
@@ -847,14 +852,14 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     for (; first + 128 <= split; first += 128) {
         const double2 g1 = grid_at(first + 64);
         if (!CHECK) {
-            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
         } else {
             unsigned long long viol2 = 0;
-            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, cY2, a1, wc, viol2, nodes_v, hint_v);
+            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, hcY2, a1, wc, viol2, nodes_v, hint_v);
             if (viol) break;                           // the first half fails the check: nothing of this trip counts
             if (viol2) {                               // only the second half does: keep the first
                 accm = a1;
@@ -867,7 +872,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         }
     }
     if (!(CHECK && viol) && first + 64 <= split) {     // odd whole wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
@@ -878,14 +883,14 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         for (; first + 128 <= whole_end; first += 128) {
             const double2 g1 = grid_at(first + 64);
             if (!CHECK) {
-                accm = lean_step_top<MODE, false, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+                accm = lean_step_top<MODE, false, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
                 g0 = grid_at(first + 128);
-                accm = lean_step_top<MODE, false, POLY>(g1, top, cX, khcX, cY2, accm, wc, viol);
+                accm = lean_step_top<MODE, false, POLY>(g1, top, cX, khcX, hcY2, accm, wc, viol);
             } else {
                 unsigned long long viol2 = 0;
-                const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+                const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
                 const double2 g2 = grid_at(first + 128);
-                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, cY2, a1, wc, viol2);
+                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, hcY2, a1, wc, viol2);
                 if (viol) break;
                 if (viol2) {
                     accm = a1;
@@ -898,7 +903,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             }
         }
         if (!(CHECK && viol) && first + 64 <= whole_end) {
-            const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, khcX, cY2, accm, wc, viol);
+            const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
             if (!(CHECK && viol)) {
                 accm = a1;
                 first += 64;
@@ -916,10 +921,10 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         if (TOP && top_phase) {
             // an idle lane re-evaluates this iteration's first point (lane 0 is always live) with weight 0
             if (!live) g = make_double2(uniform(g0.x), 0.0);
-            a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, khcX, cY2, accm, wc, viol);
+            a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, khcX, hcY2, accm, wc, viol);
         } else {
             if (!live) g = make_double2(0.0, 0.0);     // an idle lane re-evaluates grid point 0 with weight 0
-            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, khcX, cY2, accm, wc, viol, nodes_v, hint_v);
+            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
         }
         if (!(CHECK && viol)) {
             accm = a1;
