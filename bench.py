@@ -55,10 +55,17 @@ def algorithmic_bytes(n_prof, n_alt, n_freq, grid_points, per_profile_alt=False)
                 + n_prof * n_freq)
 
 
-def algorithmic_flops(vh, den, n_points_per_row):
+def integrated_pairs(vh, alt):
+    """Pairs whose trace is an integral over the grid: a finite virtual height above the bottom of the profile.
+    (Where the cutoff is exceeded at the bottom level already - X mode below the gyrofrequency - the reference's
+    grid collapses onto that level and the answer is min(alt) + 1e-14 km: finite, but no work, and not counted.)"""
+    return np.isfinite(vh) & (vh - float(np.min(alt)) > 1e-9)
+
+
+def algorithmic_flops(vh, den, n_points_per_row, alt):
     """68 * n_points per reflecting pair + 6 * K per pair."""
     k = np.argmax(den, axis=1).astype(np.float64)
-    reflecting = np.isfinite(vh).sum(axis=1).astype(np.float64)
+    reflecting = integrated_pairs(vh, alt).sum(axis=1).astype(np.float64)
     return float((FLOPS_PER_POINT * np.asarray(n_points_per_row, dtype=np.float64) * reflecting).sum()
                  + (FLOPS_PER_LEVEL * k * vh.shape[1]).sum())
 
@@ -316,7 +323,7 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
         abytes = algorithmic_bytes(p_gpu, alt.size, n_freq, grid_points)
-        aflops = algorithmic_flops(vh, den, n_points_row)
+        aflops = algorithmic_flops(vh, den, n_points_row, alt)
         traffic, traffic_src = None, None
         prof_json = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof_json):
@@ -346,7 +353,8 @@ def main():
                        "parallelism": (f"profile shards x{world}, one process per GPU, all_gather of vh rows over "
                                        f"{'RCCL' if backend == 'nccl' else backend}") if world > 1 else "single GPU"},
             "world_size_seen": world_seen, "backend": backend if world > 1 else None,
-            "reflecting_fraction": float(np.isfinite(vh).mean()),
+            "reflecting_fraction": float(integrated_pairs(vh, alt).mean()),
+            "finite_fraction": float(np.isfinite(vh).mean()),
             "workgroups_per_cu": ctx.occupancy(alt.size, default_tier),
             "kernel_ms": k_ms,
             # the FP64 vector ALU (not MFMA, not HBM) binds this path, so the primary

@@ -1191,6 +1191,34 @@ __device__ __forceinline__ double one_level_term(const Node* nodes, const BlockI
     return (term == term) ? term : 0.0;
 }
 
+// A grid that collapses onto the bottom level.  When the cutoff is exceeded at level 0 already (in X mode: every
+// frequency below the gyrofrequency there, X + Y > 1 with no plasma at all) the reference's reflection height is
+// alt[0] - 1e-6 (:407 on the left clamp), its grid z_i = m_i span + alt[0] with span = -1e-6 lies at or below
+// alt[0], np.interp clamps every point to level 0, and the sum is mu'(level 0) times the telescoped thicknesses
+//   S = (z_last - z_0) + 1e-6          (:413-416; the differences of neighbours are exact, Sterbenz),
+// a few 1e-15 km - or NaN when mu'(level 0) is.  No loop over the grid is needed for that: in the config-4 sweep
+// (0.5 - 16 MHz, f_H up to 1.7 MHz) 5 % of the pairs are of this kind, and through the generic loop they took
+// 15 % of the kernel's time.  Fast tier only; returns false (generic loop) where S is so close to zero that the
+// reference's own "sum == 0 -> NaN" test (:290) hangs on the order of its additions (alt[0] == 0).
+template <int MODE, int TIER>
+__device__ __forceinline__ bool collapsed_grid_sum(const Node* nodes, const BlockInfo& info, const PairFreq& pf,
+                                                   const double* __restrict__ mult, int n_points, double h_refl,
+                                                   double well_conditioned, double* sum_out) {
+#pragma clang fp contract(off)
+    const double span = h_refl - info.a0;
+    const double z_first = mult[0] * span + info.a0;
+    const double z_last = mult[n_points - 1] * span + info.a0;
+    const double S = (z_last - z_first) + kBackoff;
+    if (!(__builtin_fabs(S) > 1e-21)) return false;
+    const bool poly = info.poly_angle != 0;
+    const double mup = info.unmag
+        ? point_mup<MODE, TIER, true>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned)
+        : point_mup<MODE, TIER, false>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned);
+    const double term = mup * S;
+    *sum_out = (term == term) ? term : 0.0;        // every term NaN: nansum gives 0 (:288)
+    return true;
+}
+
 template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
@@ -1234,7 +1262,12 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
             const PairFreq pf = pair_freq(a, f);
             double h = 0.0;
             reflects = pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h);
-            if (reflects) {
+            double collapsed = 0.0;
+            if (TIER == 1 && reflects && info.K > 1 && h < info.a0 &&
+                uniform((int)collapsed_grid_sum<MODE, TIER>(nodes, info, pf, mult, sg.n_points, h, sg.well_conditioned,
+                                                            &collapsed))) {
+                result = (c == C - 1) ? uniform(collapsed) : 0.0;
+            } else if (reflects) {
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
                 if (info.unmag)

@@ -225,6 +225,34 @@ def test_oracle_on_fresh_seeded_batch(lib):
     assert_o_mode(got, want, oracle_noise(freq, den, bmag, bpsi, alt, "O", 200))
 
 
+@pytest.mark.parametrize("n_points", [1, 200, 20000])
+def test_x_mode_below_the_gyrofrequency_grid_collapses_onto_the_bottom_level(lib, n_points):
+    """f < f_H at the bottom level: X + Y > 1 there, the reference's reflection height is alt[0] - 1e-6 and all of
+    its grid is clamped to level 0 (library.py:399-416) - the kernel answers those pairs without a loop
+    (collapsed_grid_sum).  Same masks and values as the oracle, batch launch and single-profile (chunked) launch;
+    an altitude grid that starts at 0 km (where the reference's sum cancels to nothing) keeps the generic loop."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(12, 777)
+    freq = np.linspace(0.3, 2.6, 47)                     # f_H at 80 km: 0.6 ... 1.7 MHz
+    want = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", n_points)
+    collapsed = np.isfinite(want) & (want - alt.min() < 1e-9)
+    if n_points > 1:
+        assert collapsed.any() and np.isnan(want).any() and (np.isfinite(want) & ~collapsed).any()
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n_points)
+    assert_x_mode(got, want)
+    one = lib.vertical_forward_operator(freq, den[3], bmag[3], bpsi[3], alt, "X", n_points)
+    assert_x_mode(one, want[3])
+    if n_points == 200:
+        alt0 = alt - alt[0]
+        want0 = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt0, "X", n_points)
+        got0 = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt0, "X", n_points)
+        ok = np.isfinite(want0) & (want0 > 1e-9) & np.isfinite(got0)
+        assert ok.any() and np.max(np.abs(got0[ok] - want0[ok]) / want0[ok]) <= 1e-9
+        # (the pairs whose sum cancels to +-1e-22 or exactly 0 in the reference are its own coin flips: not compared)
+        assert np.array_equal(np.isnan(got0[want0 > 1e-9]), np.isnan(want0[want0 > 1e-9]))
+
+
 def test_per_profile_altitude_rows(lib):
     g = load_golden("g5_chapman64.npz")
     alt2 = np.tile(g["alt"], (8, 1))
