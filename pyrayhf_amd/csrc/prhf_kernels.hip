@@ -610,27 +610,26 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // The angle enters as C2 = 2 cos^2 psi and the field as hY2 = Y^2 / 2: Y_L^2 = hY2 C2 and h = Y_T^2 / 2 =
 // hY2 - Y_L^2 / 2 are then one product and one FMA (through sin^2 psi: Y_T^2, Y_L^2 = Y^2 - Y_T^2, h - three).
 // The difference costs h an absolute error of 1e-16 Y^2 where psi is small - and there h itself no longer matters.
-// 29 instructions from (den, Y^2/2, C2) - with Y^2/2 = (cY2/2) b^2 (two more) 31: 16 FMA, 12 MUL, 1 ADD,
+// 28 instructions from (den, Y^2/2, C2) - with Y^2/2 = (cY2/2) b^2 (two more) 30: 16 FMA, 11 MUL, 1 ADD,
 // 2 v_rsq_f64 (the version through X needed 34).
-// khcX = 0.5 s cX (s = +1 O, -1 X) rides in a scalar register like cX and cY2.
 template <int MODE>
-__device__ __forceinline__ double group_index_lean(double den, double hY2, double C2, double cX, double khcX,
-                                                   double* a_out) {
+__device__ __forceinline__ double group_index_lean(double den, double hY2, double C2, double cX, double* a_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
     const double a = __builtin_fma(-cX, den, 1.0);             // 1 - X
     const double YL2 = hY2 * C2;                               // Y^2 cos^2 psi  (hY2 = Y^2 / 2, C2 = 2 cos^2 psi)
     const double h = __builtin_fma(-0.5, YL2, hY2);            // Y^2 sin^2 psi / 2
     const double t = a * YL2;
-    const double alpha = __builtin_fma(h, h, t * a);
+    const double ta = t * a;
+    const double alpha = __builtin_fma(h, h, ta);
     const double rbeta = rsqrt_tier<MODE>(alpha);
     const double G = __builtin_fma(sgn * alpha, rbeta, -h);    // s beta - h
     const double D = a + G;
     const double N = __builtin_fma(a, a, G);                   // D - X (1 - X)
     const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
     const double DmX = __builtin_fma(-cX, den, D);
-    const double k = __builtin_fma(khcX, den, 0.5 * sgn);      // s (1 + X) / 2
-    const double Sp1 = __builtin_fma(k, t * rbeta, 1.0);       // 1 + s t (1 + X) / (2 beta)
+    const double v = __builtin_fma(-0.5, ta, t);               // t (1 + X) / 2 = t (1 - a / 2): t a is there already
+    const double Sp1 = __builtin_fma(sgn * v, rbeta, 1.0);     // 1 + s t (1 + X) / (2 beta)
     const double Nw = N * w;
     const double q = __builtin_fma(-Nw, Nw, 1.0);              // X (1 - X) / D = 1 - mu^2
     const double U = __builtin_fma(Sp1, q, DmX);
@@ -652,7 +651,7 @@ __device__ __forceinline__ double group_index_lean(double den, double hY2, doubl
 // HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
 template <int MODE, bool CHECK, int POLY, bool HINT>
-__device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX, double khcX,
+__device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX,
                                             double hcY2, double acc, double wc, unsigned long long& viol,
                                             unsigned nodes_v, unsigned hint_v) {
 #pragma clang fp contract(fast)
@@ -705,7 +704,7 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     const double C2 = POLY == 1 ? ua.x + x * ua.y
                     : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
     double a;
-    const double mup = group_index_lean<MODE>(den, hcY2 * (b * b), C2, cX, khcX, &a);
+    const double mup = group_index_lean<MODE>(den, hcY2 * (b * b), C2, cX, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -737,7 +736,7 @@ __device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, doubl
     return t;
 }
 template <int MODE, bool CHECK, int POLY>
-__device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, double cX, double khcX, double hcY2,
+__device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, double cX, double hcY2,
                                                 double acc, double wc, unsigned long long& viol) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
@@ -746,7 +745,7 @@ __device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, 
     const double C2 = POLY == 1 ? t.q0 + m0 * t.q1
                     : (POLY == 2 ? t.q0 + m0 * (t.q1 + m0 * t.q2) : t.q0 + m0 * (t.q1 + m0 * (t.q2 + m0 * t.q3)));
     double a;
-    const double mup = group_index_lean<MODE>(den, Y * Y, C2, cX, khcX, &a);
+    const double mup = group_index_lean<MODE>(den, Y * Y, C2, cX, &a);
     (void)hcY2;
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
@@ -781,7 +780,6 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     first = uniform(first); end = uniform(end); last_special = uniform(last_special);
     span = uniform(span); a0 = uniform(a0); kj = uniform(kj); cX = uniform(cX);
     const double hcY2 = uniform(0.5 * cY2);            // Y^2 / 2 = hcY2 |B|^2 (group_index_lean)
-    const double khcX = uniform((MODE == PRHF_KMODE_O ? 0.5 : -0.5) * cX);
     const double wc = CHECK ? uniform(well_conditioned) : 0.0;
     pairs = reinterpret_cast<const double2*>(
         ((unsigned long long)(unsigned)uniform((int)((unsigned long long)pairs >> 32)) << 32) |
@@ -852,14 +850,14 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     for (; first + 128 <= split; first += 128) {
         const double2 g1 = grid_at(first + 64);
         if (!CHECK) {
-            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
         } else {
             unsigned long long viol2 = 0;
-            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, khcX, hcY2, a1, wc, viol2, nodes_v, hint_v);
+            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, hint_v);
             if (viol) break;                           // the first half fails the check: nothing of this trip counts
             if (viol2) {                               // only the second half does: keep the first
                 accm = a1;
@@ -872,7 +870,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         }
     }
     if (!(CHECK && viol) && first + 64 <= split) {     // odd whole wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
+        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
@@ -883,14 +881,14 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         for (; first + 128 <= whole_end; first += 128) {
             const double2 g1 = grid_at(first + 64);
             if (!CHECK) {
-                accm = lean_step_top<MODE, false, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
+                accm = lean_step_top<MODE, false, POLY>(g0, top, cX, hcY2, accm, wc, viol);
                 g0 = grid_at(first + 128);
-                accm = lean_step_top<MODE, false, POLY>(g1, top, cX, khcX, hcY2, accm, wc, viol);
+                accm = lean_step_top<MODE, false, POLY>(g1, top, cX, hcY2, accm, wc, viol);
             } else {
                 unsigned long long viol2 = 0;
-                const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
+                const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, hcY2, accm, wc, viol);
                 const double2 g2 = grid_at(first + 128);
-                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, khcX, hcY2, a1, wc, viol2);
+                const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, hcY2, a1, wc, viol2);
                 if (viol) break;
                 if (viol2) {
                     accm = a1;
@@ -903,7 +901,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             }
         }
         if (!(CHECK && viol) && first + 64 <= whole_end) {
-            const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, khcX, hcY2, accm, wc, viol);
+            const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, hcY2, accm, wc, viol);
             if (!(CHECK && viol)) {
                 accm = a1;
                 first += 64;
@@ -921,10 +919,10 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         if (TOP && top_phase) {
             // an idle lane re-evaluates this iteration's first point (lane 0 is always live) with weight 0
             if (!live) g = make_double2(uniform(g0.x), 0.0);
-            a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, khcX, hcY2, accm, wc, viol);
+            a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, hcY2, accm, wc, viol);
         } else {
             if (!live) g = make_double2(0.0, 0.0);     // an idle lane re-evaluates grid point 0 with weight 0
-            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, khcX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
         }
         if (!(CHECK && viol)) {
             accm = a1;
