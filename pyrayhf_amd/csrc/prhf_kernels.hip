@@ -305,6 +305,7 @@ struct BlockInfo {
     int uniform;      // altitude grid is uniform below the peak
     int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too); 0: some use sin()
     int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
+    const double* heights;   // O mode with a candidate list: reflection height of every entry (they all reflect); else null
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
     double inv_step;  // 1 / level spacing (uniform grids)
@@ -1093,9 +1094,17 @@ __device__ __forceinline__ void prefix_max_in_place(double* v, int K, double* re
 // The frequencies of this profile that may reflect, in ascending index order, as a list in LDS; the others -
 // those for which the bound of pair_reflects says "escapes for certain" - get their NaN here, with coalesced
 // stores, and never become work items.  Whole workgroup; returns the list length (wave-uniform).
+//
+// O mode with `heights` given (room for one double per frequency): the list is exact.  The running maximum of
+// f_N^2 is in LDS (prefix_max_in_place) and does not depend on the frequency, so each THREAD settles one
+// frequency - a binary search for the first level above the cutoff and the three divisions of
+// reflection_height, the same IEEE operations on the same values - instead of each WAVE settling one pair later
+// on: ~2 vector instructions per pair instead of ~80, which is a sixth of a pair's cost on a 200-point grid.
+// heights[i] belongs to cand[i]; every listed frequency reflects.
 template <int THREADS>
 __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg, const double* keep,
-                                               long long pair_base, unsigned short* cand, int* cand_count) {
+                                               long long pair_base, unsigned short* cand, int* cand_count,
+                                               const Node* nodes, const double* pf2, int K, double* heights) {
     constexpr int W = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = (int)a.n_freq;
@@ -1104,11 +1113,44 @@ __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg,
     for (int base = 0; base < F; base += THREADS) {
         const int f = base + tid;
         bool may = false;
+        double h = 0.0;
         if (f < F) {
             const double* row = a.ftab + 8 * (long long)f;
-            double ub = pmax * row[4];
-            if (sg.mode == PRHF_KMODE_X) ub = ub + gmax * row[5];
-            may = !(ub < 1.0 - 1e-9);
+            if (heights) {
+#pragma clang fp contract(off)
+                // first level whose quotient exceeds 1: fl(p / f2) > 1 <=> p - f2 > f2 2^-53 (see reflection_height)
+                const double f2 = row[1];
+                const double ulp_half = f2 * 0x1p-53;
+                int lo = 0, hi = K;                     // answer in [lo, hi]; hi == K: none
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((pf2[mid] - f2) > ulp_half) hi = mid; else lo = mid + 1;
+                }
+                const int kstar = lo;
+                const double below = (kstar > 0 ? pf2[kstar - 1] : -__builtin_inf()) / f2;     // :136
+                if (kstar == K) {
+                    may = below >= 1.0;                 // == 1 exactly at the top level, else it never reaches the cutoff (:399)
+                    h = nodes[K - 1].alt;
+                } else if (kstar == 0) {
+                    may = true;
+                    h = nodes[0].alt;                   // above the cutoff at the bottom already: left clamp
+                } else {
+                    may = true;
+                    const double aj = nodes[kstar - 1].alt;
+                    if (below == 1.0) {
+                        h = aj;
+                    } else {
+                        const double col_star = pf2[kstar] / f2;
+                        const double slope = (nodes[kstar].alt - aj) / (col_star - below);
+                        h = slope * (1.0 - below) + aj;
+                    }
+                }
+                h = h - kBackoff;                       // :407
+            } else {
+                double ub = pmax * row[4];
+                if (sg.mode == PRHF_KMODE_X) ub = ub + gmax * row[5];
+                may = !(ub < 1.0 - 1e-9);
+            }
             if (!may) a.out[sg.out_off + pair_base + f] = qnan();      // never reaches the cutoff (:399)
         }
         const unsigned long long mask = __ballot(may);
@@ -1121,7 +1163,11 @@ __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg,
             if (w < wave) at += n;
             chunk += n;
         }
-        if (may) cand[at + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)f;
+        if (may) {
+            const int pos = at + __popcll(mask & ((1ull << lane) - 1ull));
+            cand[pos] = (unsigned short)f;
+            if (heights) heights[pos] = h;
+        }
         __syncthreads();
         total += chunk;
     }
@@ -1163,7 +1209,11 @@ __device__ __forceinline__ PairFreq pair_freq(const KArgs& a, int f) {
 template <int MODE>
 __device__ __forceinline__ bool pair_reflects(const Node* nodes, const double* pf2, const double* gb,
                                               const BlockInfo& info, const double* keep, const PairFreq& pf,
-                                              int lane, double* h_out) {
+                                              int lane, int list_pos, double* h_out) {
+    if (info.heights) {                            // settled when the candidate list was made (list_candidates)
+        *h_out = uniform(info.heights[list_pos]);
+        return true;
+    }
     if (info.K > 1 && info.n_cand < 0) {           // (a candidate list has applied this bound already)
         double ub = keep[kKeepPf2Max] * pf.inv_f2;
         if (MODE == PRHF_KMODE_X) ub = ub + keep[kKeepGbMax] * pf.inv_f;
@@ -1259,7 +1309,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
         if (!info.bad) {
             const PairFreq pf = pair_freq(a, f);
             double h = 0.0;
-            reflects = pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h);
+            reflects = pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, t, &h);
             double collapsed = 0.0;
             if (TIER == 1 && reflects && info.K > 1 && h < info.a0 &&
                 uniform((int)collapsed_grid_sum<MODE, TIER>(nodes, info, pf, mult, sg.n_points, h, sg.well_conditioned,
@@ -1350,7 +1400,7 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
             if (sub == q) my_f = f;
             const PairFreq pf = pair_freq(a, f);
             double h = 0.0;
-            if (!pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, &h)) continue;   // (K > 1 on this path)
+            if (!pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, e0 + q, &h)) continue;   // (K > 1 on this path)
             const double span = uniform(h - a0);
             const double kj = uniform(by_hint ? span * info.inv_w * (1.0 - 1e-11) : span * info.inv_step);
             const bool in_table = by_hint ? (kj < (double)kHintBuckets && info.inv_w > 0.0)
@@ -1430,9 +1480,15 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     info.n_cand = -1;
+    info.heights = nullptr;
     if (a.ftab && !a.no_candidates && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
+    {
+        // (O mode never reads g_p |B| per level again: its array holds the reflection heights)
+        double* heights = (sg.mode == PRHF_KMODE_O && a.n_freq <= a.n_alt) ? gb : nullptr;
         info.n_cand = list_candidates<THREADS>(a, sg, kept_scalars<THREADS>(red), prof_local * a.n_freq, cand,
-                                               cand_count);
+                                               cand_count, nodes, pf2, info.K, heights);
+        info.heights = heights;
+    }
 #ifdef PRHF_TRACE
     const unsigned long long t_staged = wall_clock64();
 #else
