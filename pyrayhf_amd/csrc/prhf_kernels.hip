@@ -766,8 +766,8 @@ struct LeanResult {
     int first;      // first grid point not consumed
 };
 
-// CHECK (default O-mode arithmetic): stop in front of the first trip that holds a point with
-// 1 - X <= well_conditioned; the caller continues from there in the reference's operation order.
+// CHECK (default O-mode arithmetic): stop in front of the first point with 1 - X <= well_conditioned; the
+// caller continues from there in the reference's operation order.
 // TOP: with the top-segment phase (long grids on a uniform altitude grid); the short-grid callers use the
 // variant without it, which needs 24 fewer vector registers around the call.
 template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
@@ -859,10 +859,16 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
             const double2 g2 = grid_at(first + 128);
             const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, hint_v);
-            if (viol) break;                           // the first half fails the check: nothing of this trip counts
-            if (viol2) {                               // only the second half does: keep the first
-                accm = a1;
-                first += 64;
+            if (viol) {                                // keep the points in front of the first one that fails
+                const int L = __ffsll((long long)viol) - 1;
+                if (lane < L) accm = a1;
+                first += L;
+                break;
+            }
+            if (viol2) {
+                const int L = __ffsll((long long)viol2) - 1;
+                accm = lane < L ? a2 : a1;
+                first += 64 + L;
                 viol = viol2;
                 break;
             }
@@ -876,6 +882,10 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
             accm = a1;
             first += 64;
             g0 = grid_at(first);
+        } else {
+            const int L = __ffsll((long long)viol) - 1;
+            if (lane < L) accm = a1;
+            first += L;
         }
     }
     if (TOP && top_phase && !(CHECK && viol)) {        // the same two loops over the top segment
@@ -890,10 +900,16 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
                 const double a1 = lean_step_top<MODE, true, POLY>(g0, top, cX, hcY2, accm, wc, viol);
                 const double2 g2 = grid_at(first + 128);
                 const double a2 = lean_step_top<MODE, true, POLY>(g1, top, cX, hcY2, a1, wc, viol2);
-                if (viol) break;
+                if (viol) {
+                    const int L = __ffsll((long long)viol) - 1;
+                    if (lane < L) accm = a1;
+                    first += L;
+                    break;
+                }
                 if (viol2) {
-                    accm = a1;
-                    first += 64;
+                    const int L = __ffsll((long long)viol2) - 1;
+                    accm = lane < L ? a2 : a1;
+                    first += 64 + L;
                     viol = viol2;
                     break;
                 }
@@ -907,6 +923,10 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
                 accm = a1;
                 first += 64;
                 g0 = grid_at(first);
+            } else {
+                const int L = __ffsll((long long)viol) - 1;
+                if (lane < L) accm = a1;
+                first += L;
             }
         }
     }
@@ -928,6 +948,11 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
         if (!(CHECK && viol)) {
             accm = a1;
             first = end;
+        } else {
+            // (an idle lane copies a live point of lower index, so the first failing lane is a live one)
+            const int L = __ffsll((long long)viol) - 1;
+            if (lane < L) accm = a1;
+            first += L;
         }
     }
     LeanResult r;
@@ -958,13 +983,13 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
         // Lean main loop of the common case (slowly turning field; uniform altitude grid, or any grid
         // through the hint table).  Fast tier: it takes every grid point of the range, the last one of the
         // grid (thickness 1e-6 km) included, so nothing is left for the generic loop below.  Default O-mode
-        // arithmetic: it takes the points up to the last 64 of the range - those, and everything from the
-        // first trip on that holds a point with 1 - X <= well_conditioned, go through the generic loop in the
-        // reference's operation order.
+        // arithmetic: it stops in front of the first point with 1 - X <= well_conditioned (and never takes the
+        // last point of the grid); everything from there on goes through the generic loop in the reference's
+        // operation order - usually a handful of points next to the reflection height, one wave-iteration.
 #pragma clang fp contract(fast)
         first = uniform(first);
         const bool to_grid_end = i1 == n_points;
-        const int lean_end = uniform(TIER == 1 ? i1 : (i1 - 64 > first ? i1 - 64 : first));
+        const int lean_end = uniform((TIER == 1 || !to_grid_end) ? i1 : i1 - 1);
         const int last_special = (TIER == 1 && to_grid_end) ? last : -1;
         // index scale: (z - a0) / step = m * kj on a uniform grid, hint buckets per unit of m otherwise
         const bool by_hint = !info.uniform;
