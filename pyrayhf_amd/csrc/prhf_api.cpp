@@ -397,7 +397,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 #ifdef PRHF_TRACE
     // diagnostics build (tools/wave_trace.py): per-wave wall-clock stamps of this launch, dumped to $PRHF_TRACE_FILE
     static DevBuf trace_buf;
-    const size_t trace_words = (size_t)blocks * kWavesPerBlock * 3;   // start, end, staged
+    const size_t trace_words = (size_t)blocks * kWavesPerBlock * 6;   // start, end, staged, and three staging marks
     if (std::getenv("PRHF_TRACE_FILE")) {
         if ((rc = ensure(c, trace_buf, trace_words * 8)) != PRHF_OK) return rc;
         HIP_TRY(hipMemsetAsync(trace_buf.p, 0, trace_words * 8, c->stream));

@@ -321,6 +321,17 @@ __device__ __forceinline__ const double* kept_scalars(const double* red) { retur
 
 constexpr int kHintBuckets = PRHF_HINT_BUCKETS;
 
+// -DPRHF_TRACE builds: wall-clock marks of the staging phases of the current block (thread 0 writes them)
+#ifdef PRHF_TRACE
+__device__ __forceinline__ unsigned long long* trace_marks() {
+    __shared__ unsigned long long marks[4];
+    return marks;
+}
+#define PRHF_MARK(i) do { if (threadIdx.x == 0) trace_marks()[i] = wall_clock64(); } while (0)
+#else
+#define PRHF_MARK(i) do { } while (0)
+#endif
+
 // Stage one profile into LDS.  Every thread of the block calls this.
 template <int TIER, int THREADS>
 __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ den,
@@ -375,6 +386,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         amin = fmin(amin, red[2 * W + w]);
         fm = fmin(fm, red[3 * W + w]);
     }
+    PRHF_MARK(0);
     BlockInfo info;
     info.K = uniform((bi == 0x7fffffff) ? 0 : bi);      // library.py:371-375: levels [0, argmax)
     // every thread holds the same reduced value and writes it: a wave reads back what it wrote itself
@@ -1503,7 +1515,9 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
+    PRHF_MARK(1);
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
+    PRHF_MARK(2);
     info.n_cand = -1;
     info.heights = nullptr;
     if (a.ftab && !a.no_candidates && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
@@ -1589,10 +1603,13 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         (void)t_staged;
 #ifdef PRHF_TRACE
         if (a.trace && (threadIdx.x & 63) == 0) {
-            unsigned long long* t = a.trace + (bid * (THREADS / 64) + (threadIdx.x >> 6)) * 3;
+            unsigned long long* t = a.trace + (bid * (THREADS / 64) + (threadIdx.x >> 6)) * 6;
             t[0] = t_start;
             t[1] = wall_clock64();
             t[2] = t_staged;
+            t[3] = trace_marks()[0];           // argmax known; [4] nodes staged; [5] running maximum done
+            t[4] = trace_marks()[1];
+            t[5] = trace_marks()[2];
         }
 #endif
         if (a.queue == nullptr) break;

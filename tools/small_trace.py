@@ -14,7 +14,7 @@ t = [torch.as_tensor(x, device=dev) for x in (f174, *day)]
 for mode, n in (("X", 20000), ("O", 200)):
     for _ in range(3):
         library.vertical_forward_operator(*t, mode, n)
-    w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 3).astype(np.float64) / 100.0
+    w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 6).astype(np.float64) / 100.0
     t0 = w[:, :, 0].min()
     print(json.dumps({"case": f"{mode}/{n}", "workgroups": int(w.shape[0]), "kernel_ms_events": _native.context(0).last_kernel_ms(),
                       "first_start_us": 0.0, "last_start_us": float(w[:, :, 0].max() - t0),

@@ -11,7 +11,7 @@ alt, den, bmag, bpsi = synth.chapman_profiles(12500, 20260004)
 t = [torch.as_tensor(x, device=dev) for x in (synth.sounder_frequencies(4), den, bmag, bpsi, alt)]
 for _ in range(2):
     library.vertical_forward_operator(*t, "X", 20000)
-w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 3).astype(np.float64) / 100.0  # us (100 MHz wall clock): start, end, staged
+w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 6).astype(np.float64) / 100.0  # us (100 MHz wall clock): start, end, staged
 t0 = w[:, :, 0].min()
 start, end = w[:, :, 0] - t0, w[:, :, 1] - t0
 wg_start, wg_end = start.min(axis=1), end.max(axis=1)

@@ -11,15 +11,19 @@ alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
 t = [torch.as_tensor(x, device=dev) for x in (synth.sounder_frequencies(3), den, bmag, bpsi, alt)]
 for _ in range(2):
     library.vertical_forward_operator(*t, "O", 200)
-w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 3).astype(np.float64) / 100.0  # us: start, end, staged
+w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 6).astype(np.float64) / 100.0  # us: start, end, staged
 t0 = w[:, :, 0].min()
 start, end, staged = w[:, :, 0] - t0, w[:, :, 1] - t0, w[:, :, 2] - t0
 life = end.max(axis=1) - start.min(axis=1)
 stage = (staged - start).max(axis=1)
 items = life - stage
+marks = w[:, 0, 3:6] - t0                                   # argmax known, nodes staged, running maximum done
+phases = {"argmax_us": float((marks[:, 0] - start[:, 0]).mean()), "nodes_us": float((marks[:, 1] - marks[:, 0]).mean()),
+          "running_max_us": float((marks[:, 2] - marks[:, 1]).mean()),
+          "candidates_us": float((staged[:, 0] - marks[:, 2]).mean())}
 print(json.dumps({"blocks": int(w.shape[0]), "kernel_us": float(end.max()),
                   "block_life_us": {"mean": float(life.mean()), "p10": float(np.percentile(life, 10)), "p90": float(np.percentile(life, 90))},
-                  "staging_us": {"mean": float(stage.mean()), "p10": float(np.percentile(stage, 10)), "p90": float(np.percentile(stage, 90))},
+                  "staging_phases": phases, "staging_us": {"mean": float(stage.mean()), "p10": float(np.percentile(stage, 10)), "p90": float(np.percentile(stage, 90))},
                   "item_loop_us": {"mean": float(items.mean())},
                   "wave_slot_fill_in_item_loop": float(((end - staged).sum()) / (8 * items.sum())),
                   "sum_of_block_lives_over_kernel_x_slots": float(life.sum() / (end.max() * 512))}))
