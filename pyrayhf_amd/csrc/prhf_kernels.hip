@@ -1692,24 +1692,45 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
                               double* __restrict__ mu_out, double* __restrict__ mup_out,
                               unsigned long long* track) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     double ymax = 0.0;
     int seen = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double mu, mup;
-        const double y = Y[i];
+    auto one = [&](double x, double y, double p, double* mu, double* mup) {
         const double ay = fabs(y);
         ymax = fmax(ymax, ay);
         seen |= (ay == ay) ? 1 : 0;
         if (unmag) {
-            index_unmagnetised(X[i], &mu, &mup);
+            index_unmagnetised(x, mu, mup);
         } else if (TIER == 0) {
-            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(X[i], y, psi[i], &mu, &mup);
-            else index_faithful<PRHF_KMODE_X>(X[i], y, psi[i], &mu, &mup);
+            if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(x, y, p, mu, mup);
+            else index_faithful<PRHF_KMODE_X>(x, y, p, mu, mup);
         } else {
-            const double sn = sin(psi[i] * kDegToRad);
-            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(X[i], y * y, sn * sn, &mu, &mup);
-            else index_fast<PRHF_KMODE_X>(X[i], y * y, sn * sn, &mu, &mup);
+            const double sn = sin(p * kDegToRad);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, sn * sn, mu, mup);
+            else index_fast<PRHF_KMODE_X>(x, y * y, sn * sn, mu, mup);
         }
+    };
+    // two elements per thread and pass where the five arrays allow 16-byte accesses (wider loads in flight, half
+    // the address arithmetic); results are written once and never read back here: streaming stores
+    const bool wide = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(psi) |
+                        reinterpret_cast<uintptr_t>(mu_out) | reinterpret_cast<uintptr_t>(mup_out)) & 15) == 0;
+    const long long n2 = wide ? n >> 1 : 0;
+    const double2* X2 = reinterpret_cast<const double2*>(X);
+    const double2* Y2 = reinterpret_cast<const double2*>(Y);
+    const double2* P2 = reinterpret_cast<const double2*>(psi);
+    for (long long i = tid; i < n2; i += stride) {
+        const double2 x = X2[i], y = Y2[i], ps = P2[i];
+        double mu0, mup0, mu1, mup1;
+        one(x.x, y.x, ps.x, &mu0, &mup0);
+        one(x.y, y.y, ps.y, &mu1, &mup1);
+        typedef double vec2 __attribute__((ext_vector_type(2)));
+        const vec2 m = {mu0, mu1}, mp = {mup0, mup1};
+        __builtin_nontemporal_store(m, reinterpret_cast<vec2*>(mu_out) + i);
+        __builtin_nontemporal_store(mp, reinterpret_cast<vec2*>(mup_out) + i);
+    }
+    for (long long i = 2 * n2 + tid; i < n; i += stride) {
+        double mu, mup;
+        one(X[i], Y[i], psi[i], &mu, &mup);
         mu_out[i] = mu;
         mup_out[i] = mup;
     }
