@@ -63,20 +63,82 @@ static_assert(sizeof(Node) == PRHF_NODE_BYTES, "node size");
 
 __device__ __forceinline__ double qnan() { return __builtin_nan(""); }
 
+// Cross-lane exchanges without address registers.  __shfl_xor / __shfl_up compile to ds_bpermute_b32 with the
+// source lane in a VGPR; inside the persistent loop the compiler hoists those twelve lane patterns out of the
+// loop, runs out of registers and reloads them from scratch one by one where they are used - the running maximum
+// of a profile waited 2 us for six such reloads.  ds_swizzle (lane ^ 1..16), v_permlane32_swap (the two halves
+// of the wave, gfx950) and DPP row shifts carry the pattern in the instruction.
+template <int OFF>
+__device__ __forceinline__ double lane_xor(double v) {          // the value of lane ^ OFF, OFF = 1, 2, 4, 8, 16
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (OFF << 10) | 0x1f);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (OFF << 10) | 0x1f);
+    return __hiloint2double(hi, lo);
+}
+template <int OFF>
+__device__ __forceinline__ int lane_xor(int v) {
+    return __builtin_amdgcn_ds_swizzle(v, (OFF << 10) | 0x1f);
+}
+// own[l] and other[l] are v[l] and v[l ^ 32] in SOME order (the lower half gets them as named, the upper half
+// swapped): enough for any symmetric combination
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void halves(double v, double* own, double* other) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const uint2v a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const uint2v b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    *own = __hiloint2double((int)b.x, (int)a.x);
+    *other = __hiloint2double((int)b.y, (int)a.y);
+}
+__device__ __forceinline__ void halves(int v, int* own, int* other) {
+    const uint2v a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    *own = (int)a.x;
+    *other = (int)a.y;
+}
+// (the order of the steps - 32, 16, ..., 1 - is the order the shuffle versions had: same sums bit for bit)
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    double p, q;
+    halves(v, &p, &q);
+    v = fmax(p, q);
+    v = fmax(v, lane_xor<16>(v)); v = fmax(v, lane_xor<8>(v)); v = fmax(v, lane_xor<4>(v));
+    v = fmax(v, lane_xor<2>(v)); v = fmax(v, lane_xor<1>(v));
     return v;
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    double p, q;
+    halves(v, &p, &q);
+    v = fmin(p, q);
+    v = fmin(v, lane_xor<16>(v)); v = fmin(v, lane_xor<8>(v)); v = fmin(v, lane_xor<4>(v));
+    v = fmin(v, lane_xor<2>(v)); v = fmin(v, lane_xor<1>(v));
     return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    double p, q;
+    halves(v, &p, &q);
+    v = p + q;
+    v = v + lane_xor<16>(v); v = v + lane_xor<8>(v); v = v + lane_xor<4>(v);
+    v = v + lane_xor<2>(v); v = v + lane_xor<1>(v);
     return v;
+}
+// Inclusive running maximum over the lanes, and the same shifted up by one lane (-inf into lane 0): DPP row
+// shifts inside the rows of 16, row_bcast:15 / :31 across them.
+#define PRHF_DPP_MAX(v, ctrl, rows) do {                                                                              \
+        const double ninf_ = -__builtin_inf();                                                                       \
+        const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(ninf_), __double2loint(v), ctrl, rows, 0xf, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(ninf_), __double2hiint(v), ctrl, rows, 0xf, false); \
+        v = fmax(v, __hiloint2double(hi_, lo_));                                                                     \
+    } while (0)
+__device__ __forceinline__ double wave_scan_max(double v) {
+    PRHF_DPP_MAX(v, 0x111, 0xf);    // row_shr:1
+    PRHF_DPP_MAX(v, 0x112, 0xf);    // row_shr:2
+    PRHF_DPP_MAX(v, 0x114, 0xf);    // row_shr:4
+    PRHF_DPP_MAX(v, 0x118, 0xf);    // row_shr:8
+    PRHF_DPP_MAX(v, 0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+    PRHF_DPP_MAX(v, 0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double wave_shift_up_1(double v, double into_lane_0) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(into_lane_0), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(into_lane_0), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);              // wave_shr:1
 }
 
 // Wave-uniform values computed by the vector ALU live in VGPRs unless told otherwise; moving
@@ -359,11 +421,22 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     }
     double fm = __builtin_inf();
     for (int i = tid; i < n_freq; i += THREADS) fm = fmin(fm, fabs(freq[i]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(bv, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    {
+        // first occurrence of the maximum: a symmetric choice between the two halves, then lane ^ 16 ... ^ 1
+        double v0, v1;
+        int i0, i1;
+        halves(bv, &v0, &v1);
+        halves(bi, &i0, &i1);
+        const bool second = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = second ? v1 : v0;
+        bi = second ? i1 : i0;
+#define PRHF_ARGMAX_STEP(OFF) do {                                                  \
+            const double ov = lane_xor<OFF>(bv);                                    \
+            const int oi = lane_xor<OFF>(bi);                                       \
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }             \
+        } while (0)
+        PRHF_ARGMAX_STEP(16); PRHF_ARGMAX_STEP(8); PRHF_ARGMAX_STEP(4); PRHF_ARGMAX_STEP(2); PRHF_ARGMAX_STEP(1);
+#undef PRHF_ARGMAX_STEP
     }
     amin = wave_min(amin);
     fm = wave_min(fm);
@@ -1107,14 +1180,8 @@ __device__ __forceinline__ void prefix_max_in_place(double* v, int K, double* re
     double mine = -__builtin_inf();
     for (int i = 0; i < per; ++i)
         if (base + i < K) mine = fmax(mine, v[base + i]);
-    double inc = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(inc, off);
-        if (lane >= off) inc = fmax(inc, o);
-    }
-    double before = __shfl_up(inc, 1);             // maximum of the lower lanes' levels
-    if (lane == 0) before = -__builtin_inf();
+    const double inc = wave_scan_max(mine);
+    double before = wave_shift_up_1(inc, -__builtin_inf());     // maximum of the lower lanes' levels
     if (lane == 63) red[wave] = inc;               // (rows 0..3 of `red` were phase-1 scratch of stage_profile: free now)
     __syncthreads();
 #pragma unroll
@@ -1454,8 +1521,10 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
                     !uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
                     shared = true;
                     tail_mask |= 1u << q;
-                    double s = r.acc + __shfl_xor(r.acc, 32);
-                    s = s + __shfl_xor(s, 16);
+                    double s0, s1;
+                    halves(r.acc, &s0, &s1);
+                    double s = s0 + s1;
+                    s = s + lane_xor<16>(s);
                     if (sub == q) { my_fhz = pf.f_hz; my_f2 = pf.f2; my_h = h; my_sum = s; }
                 }
             }
@@ -1493,8 +1562,8 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
             if (!(live && term == term)) term = 0.0;                             // nansum
             // sum over the 16 lanes of each pair: its tail terms and its main loop's four-lane partial sums
             double total = term + my_sum;
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) total = total + __shfl_xor(total, off);
+            total = total + lane_xor<8>(total); total = total + lane_xor<4>(total);
+            total = total + lane_xor<2>(total); total = total + lane_xor<1>(total);
             shared_vh = (total != 0.0) ? total + alt_min : qnan();               // :290-292
         }
         // lanes 0, 16, 32, 48 store their pair's result
