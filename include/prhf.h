@@ -249,6 +249,11 @@ int prhf_sync(prhf_ctx* ctx);
  * context's stream.  Synchronises on the stop event. */
 int prhf_last_kernel_ms(prhf_ctx* ctx, double* ms);
 
+/* The same for the most recent launches, oldest first: at most `capacity` of them (the context remembers 64);
+ * *n = how many were written.  One synchronisation, on the newest launch - what a caller needs that enqueues a
+ * series of launches and wants every one's device time without a host round trip between them (bench.py). */
+int prhf_recent_kernel_ms(prhf_ctx* ctx, double* ms, int32_t capacity, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,8 @@ _PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_int32)]),
     "prhf_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "prhf_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "prhf_recent_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32,
+                                             ctypes.POINTER(ctypes.c_int32)]),
 }
 
 _lib = None
@@ -255,6 +257,14 @@ class Context:
         ms = ctypes.c_double(0.0)
         raise_for(self._lib.prhf_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def recent_kernel_ms(self, count=64):
+        """Device times [ms] of the most recent launches (at most 64 are remembered), oldest first; one
+        synchronisation on the newest."""
+        buf = (ctypes.c_double * max(int(count), 1))()
+        n = ctypes.c_int32(0)
+        raise_for(self._lib.prhf_recent_kernel_ms(self._h, buf, int(count), ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
 
 
 _tls = threading.local()

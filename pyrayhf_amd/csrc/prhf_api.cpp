@@ -83,14 +83,30 @@ class DeviceScope {
     DeviceScope device_scope_(dev);  \
     HIP_TRY(device_scope_.error())
 
+hipError_t create_events(hipEvent_t* ev, int n) {
+    for (int i = 0; i < n; ++i) {
+        const hipError_t e = hipEventCreate(&ev[i]);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace
 
 struct prhf_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // start / stop events of the most recent launches, a ring: a caller that enqueues many launches without
+    // synchronising can still read every one's device time afterwards (prhf_recent_kernel_ms)
+    static constexpr int kTimingRing = 64;
+    hipEvent_t ring0[kTimingRing] = {}, ring1[kTimingRing] = {};
+    unsigned long long n_timed = 0;    // launches timed so far
+    int slot = 0;                      // ring slot of the launch being enqueued / enqueued last
     bool timed = false;
+    hipEvent_t begin_ev() { slot = (int)(n_timed % kTimingRing); return ring0[slot]; }
+    hipEvent_t end_ev() const { return ring1[slot]; }
+    void mark_timed() { ++n_timed; timed = true; }
     int math = PRHF_MATH_AUTO;
     int cu_count = 256;
     DevBuf arena;     // staged host inputs + output
@@ -373,7 +389,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         d_cost = post->cost ? p0 + n_freq + out_elems : nullptr;
     }
 
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     if (want_pairs) {
         const bool stable = (flags & PRHF_FLAG_GRID_STABLE) != 0;
         if (!(stable && c->pairs.p && c->pairs_src == a.mult && c->pairs_len == mult_len)) {
@@ -425,8 +441,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 #endif
     if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     c->status_pending = true;
 
     // small results come back through the pinned buffer too (its upper half; the inputs of a call this small
@@ -489,7 +505,8 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     c->device = device;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
+        (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 2 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
             hipSuccess ||
@@ -524,8 +541,10 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->h_pack) (void)hipHostFree(c->h_pack);
     if (c->d_words) (void)hipFree(c->d_words);
     if (c->h_words) (void)hipHostFree(c->h_words);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < prhf_ctx::kTimingRing; ++i) {
+        if (c->ring0[i]) (void)hipEventDestroy(c->ring0[i]);
+        if (c->ring1[i]) (void)hipEventDestroy(c->ring1[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PRHF_OK;
@@ -540,7 +559,7 @@ int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream, int32_t borrow) {
     // Scratch buffers are reused across launches: work on the new stream must come after the last launch on
     // the old one.  Ordered through the event recorded behind that launch, not by synchronising the old
     // stream - a borrowed stream may have been destroyed by its owner since.
-    if (c->timed) HIP_TRY(hipStreamWaitEvent(next, c->ev1, 0));
+    if (c->timed) HIP_TRY(hipStreamWaitEvent(next, c->end_ev(), 0));
     c->stream = next;
     return PRHF_OK;
 }
@@ -616,11 +635,11 @@ int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double*
         HIP_TRY(hipMemcpyAsync(base + 2 * n, psi_deg, bytes, hipMemcpyHostToDevice, c->stream));
         dX = base; dY = base + n; dP = base + 2 * n; dMu = base + 3 * n; dMup = base + 4 * n;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_mu_mup(dX, dY, dP, n, mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
                                 c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dMu, dMup, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(mu_out, dMu, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(mup_out, dMup, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -652,12 +671,12 @@ int prhf_find_vh_f64(prhf_ctx* c, const double* X, const double* Y, const double
             HIP_TRY(hipMemcpyAsync(base + k * n, src[k], (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
         dX = base; dY = base + n; dP = base + 2 * n; dD = base + 3 * n; dV = base + 4 * n;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_find_vh(dX, dY, dP, dD, n_rows, n_cols, alt_min,
                                  mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
                                  c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dV, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     if (!dev) HIP_TRY(hipMemcpyAsync(vh_out, dV, (size_t)n_rows * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PRHF_OK;
@@ -712,10 +731,10 @@ int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const do
         a.out_dist = d_out + 4 * fn; a.out_alt = d_out + 5 * fn; a.out_crit = d_out + 6 * fn;
         a.out_ind = reinterpret_cast<long long*>(d_out + 7 * fn);
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_regrid(a, prhf::lds_bytes_for(n_alt), c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     c->status_pending = true;
     if (!dev) {
         double* host[7] = {out_freq, out_den, out_bmag, out_bpsi, out_dist, out_alt, out_crit};
@@ -752,10 +771,10 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
         dR = residual_out ? base + pf + n_freq : nullptr;
         dC = cost_out ? base + 2 * pf + n_freq : nullptr;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_residual(dM, dO, n_prof, (int)n_freq, dR, dC, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     if (!dev) {
         if (residual_out) HIP_TRY(hipMemcpyAsync(residual_out, dR, pf * 8, hipMemcpyDeviceToHost, c->stream));
         if (cost_out) HIP_TRY(hipMemcpyAsync(cost_out, dC, (size_t)n_prof * 8, hipMemcpyDeviceToHost, c->stream));
@@ -875,10 +894,10 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         a.prof_info = static_cast<double*>(c->partial.p);
         a.n_prof = n_prof;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_snell(a, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    c->mark_timed();
     c->status_pending = true;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(out, a.out, PRHF_SNELL_OUTPUTS * (size_t)n_rays * 8, hipMemcpyDeviceToHost, c->stream));
@@ -959,10 +978,27 @@ int prhf_last_kernel_ms(prhf_ctx* c, double* ms) {
     if (!c || !ms) return fail(PRHF_EINVAL, "null pointer");
     if (!c->timed) return fail(PRHF_EINVAL, "no launch has been timed on this context");
     ENTER_DEVICE(c->device);
-    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventSynchronize(c->end_ev()));
     float t = 0.f;
-    HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    HIP_TRY(hipEventElapsedTime(&t, c->ring0[c->slot], c->end_ev()));
     *ms = t;
+    return PRHF_OK;
+}
+
+int prhf_recent_kernel_ms(prhf_ctx* c, double* ms, int32_t capacity, int32_t* n_out) {
+    if (!c || !ms || !n_out || capacity < 0) return fail(PRHF_EINVAL, "null pointer or negative capacity");
+    ENTER_DEVICE(c->device);
+    long long n = (long long)std::min<unsigned long long>(c->n_timed, (unsigned long long)prhf_ctx::kTimingRing);
+    if (n > capacity) n = capacity;
+    *n_out = (int32_t)n;
+    if (n == 0) return PRHF_OK;
+    HIP_TRY(hipEventSynchronize(c->end_ev()));             // the newest; the older ones completed before it
+    for (long long i = 0; i < n; ++i) {                      // oldest first
+        const int s = (int)((c->n_timed - (unsigned long long)n + (unsigned long long)i) % prhf_ctx::kTimingRing);
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->ring0[s], c->ring1[s]));
+        ms[i] = t;
+    }
     return PRHF_OK;
 }
 

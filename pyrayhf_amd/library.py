@@ -308,16 +308,16 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     return _np_operator(freq, den, bmag, bpsi, alt, code, n_points, device, math)
 
 
-def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, device=None, math=None):
+def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, device=None, math=None, sync=True):
     """Several (profile range, mode, n_points) slices in ONE launch (BASELINE config 5).
 
     ``segments`` is a sequence of ``(prof_begin, prof_end, mode, n_points)``; profile ranges
     index the rows of the 2-D inputs.  Returns ``(P, F)`` float64; rows not covered by any segment
     are NaN.  GPU-resident torch tensors are used in place (zero copy, launched on torch's current
-    stream, synchronised before returning) and give a tensor on the same device.
+    stream, synchronised before returning unless ``sync=False``) and give a tensor on the same device.
     """
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):
-        return _torch_mixed(freq, den, bmag, bpsi, alt, segments, math)
+        return _torch_mixed(freq, den, bmag, bpsi, alt, segments, math, sync)
     f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
     d2, b2, p2 = (np.atleast_2d(_as_rows(n, x)) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi)))
     a = _as_rows("alt", alt)
@@ -392,3 +392,8 @@ def _torch_mixed(freq, den, bmag, bpsi, alt, segments, math, sync=True):
 def last_kernel_ms(device=None):
     """Device time [ms] of the most recent launch on this thread's context."""
     return _native.context(device).last_kernel_ms()
+
+
+def recent_kernel_ms(count=64, device=None):
+    """Device times [ms] of the most recent launches on this thread's context (at most 64), oldest first."""
+    return _native.context(device).recent_kernel_ms(count)

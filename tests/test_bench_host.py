@@ -21,9 +21,14 @@ def test_algorithmic_bytes_match_survey_8d():
 
 
 def test_algorithmic_flops():
-    vh = np.array([[1.0, np.nan, 2.0], [np.nan, np.nan, np.nan]])
+    alt = np.array([80.0, 81.0, 82.0, 83.0])
+    vh = np.array([[101.0, np.nan, 202.0], [np.nan, np.nan, np.nan]])
     den = np.array([[1.0, 2.0, 3.0, 1.0], [1.0, 5.0, 2.0, 1.0]])          # K = 2 and 1
-    assert bench.algorithmic_flops(vh, den, [100, 100]) == 68 * 100 * 2 + 6 * (2 + 1) * 3
+    assert bench.algorithmic_flops(vh, den, [100, 100], alt) == 68 * 100 * 2 + 6 * (2 + 1) * 3
+    # a trace that sits on the bottom of the profile (the grid collapsed onto level 0) is finite but no integral
+    vh[0, 0] = 80.0 + 3e-14
+    assert bench.integrated_pairs(vh, alt).sum() == 1
+    assert bench.algorithmic_flops(vh, den, [100, 100], alt) == 68 * 100 * 1 + 6 * (2 + 1) * 3
 
 
 def test_config5_work_list_scales_with_world_size():

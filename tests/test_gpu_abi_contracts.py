@@ -108,3 +108,27 @@ def test_tracer_reports_a_bad_device_resident_profile_index():
         if want_rc != _native.OK:
             bad = [i for i, v in enumerate(idx) if v != 0]
             assert np.isnan(o[bad, 0]).all() and "profile_index" in _native.last_error()
+
+
+def test_recent_kernel_ms_reports_every_launch_of_an_unsynchronised_series():
+    """prhf_recent_kernel_ms: five launches enqueued back to back, their device times read afterwards with one
+    synchronisation; the newest equals prhf_last_kernel_ms; the context remembers 64."""
+    import torch
+    from pyrayhf_amd import library, _native
+    g = load_golden("g5_chapman64.npz")
+    dev = torch.device("cuda:0")
+    t = {k: torch.as_tensor(g[k], device=dev) for k in ("freq", "den", "bmag", "bpsi", "alt")}
+    out = torch.empty((64, g["freq"].size), dtype=torch.float64, device=dev)
+    sizes = (200, 2000, 20000, 2000, 200)
+    for n in sizes:
+        library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", n, sync=False, out=out)
+    ctx = _native.context(0)
+    ms = ctx.recent_kernel_ms(len(sizes))
+    assert len(ms) == len(sizes) and all(m > 0.0 for m in ms)
+    assert ms[2] > ms[0] and ms[2] > ms[4]                      # the 20000-point launch is the long one
+    assert ms[-1] == ctx.last_kernel_ms()
+    assert len(ctx.recent_kernel_ms(2)) == 2 and ctx.recent_kernel_ms(2) == ms[-2:]
+    for _ in range(70):
+        library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", 200, sync=False, out=out)
+    assert len(ctx.recent_kernel_ms(1000)) == 64
+    assert library.recent_kernel_ms(3) == ctx.recent_kernel_ms(3)
