@@ -21,6 +21,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(paths):
+    """gpurun merges a new run into an existing local directory: keep, per directory, the newest file only."""
+    by_dir = {}
+    for path in paths:
+        d = os.path.dirname(path)
+        if d not in by_dir or os.path.getmtime(path) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = path
+    return sorted(by_dir.values())
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     key = sys.argv[3] if len(sys.argv) > 3 else "X_20000_12500x256"
@@ -31,7 +41,7 @@ def main():
              f"Source: `tools/profile.sh {tag}` on one MI355X, workload `{key}` ({desc}); counters are those of the "
              f"dispatches whose kernel name contains `{kernel}`.", ""]
 
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     avg_ns = None
     if stats:
         lines += ["## Kernel trace (`--kernel-trace --stats`)", "",
@@ -42,7 +52,7 @@ def main():
             if kernel in r["Name"]:
                 avg_ns = float(r["AverageNs"])
         lines.append("")
-    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    trace = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")))
     if trace:
         for r in csv.DictReader(open(trace[0])):
             if kernel in r["Kernel_Name"]:
@@ -52,7 +62,7 @@ def main():
                 break
 
     counters = collections.defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+    for path in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(path)):
             if kernel in r["Kernel_Name"]:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
