@@ -1350,8 +1350,9 @@ __device__ __forceinline__ double one_level_term(const Node* nodes, const BlockI
 //   S = (z_last - z_0) + 1e-6          (:413-416; the differences of neighbours are exact, Sterbenz),
 // a few 1e-15 km - or NaN when mu'(level 0) is.  No loop over the grid is needed for that: in the config-4 sweep
 // (0.5 - 16 MHz, f_H up to 1.7 MHz) 5 % of the pairs are of this kind, and through the generic loop they took
-// 15 % of the kernel's time.  Fast tier only; returns false (generic loop) where S is so close to zero that the
-// reference's own "sum == 0 -> NaN" test (:290) hangs on the order of its additions (alt[0] == 0).
+// 15 % of the kernel's time; in O mode they are the frequencies below the plasma frequency of the bottom level.
+// mu'(level 0) is evaluated in the tier's own arithmetic.  Returns false (generic loop) where S is so close to zero
+// that the reference's own "sum == 0 -> NaN" test (:290) hangs on the order of its additions (alt[0] == 0).
 template <int MODE, int TIER>
 __device__ __forceinline__ bool collapsed_grid_sum(const Node* nodes, const BlockInfo& info, const PairFreq& pf,
                                                    const double* __restrict__ mult, int n_points, double h_refl,
@@ -1415,7 +1416,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
             double h = 0.0;
             reflects = pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, t, &h);
             double collapsed = 0.0;
-            if (TIER == 1 && reflects && info.K > 1 && h < info.a0 &&
+            if (reflects && info.K > 1 && h < info.a0 &&
                 uniform((int)collapsed_grid_sum<MODE, TIER>(nodes, info, pf, mult, sg.n_points, h, sg.well_conditioned,
                                                             &collapsed))) {
                 result = (c == C - 1) ? uniform(collapsed) : 0.0;
@@ -1529,8 +1530,12 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
                 }
             }
             if (!shared) {                         // the general path, this pair by itself
-                const double total = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, n, 0, n,
-                                                                        pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
+                double total = 0.0;
+                // (a frequency below the plasma frequency of the bottom level: the grid collapses onto that level)
+                if (!(h < a0 && uniform((int)collapsed_grid_sum<MODE, TIER>(nodes, info, pf, mult, n, h, sg.well_conditioned,
+                                                                            &total))))
+                    total = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, n, 0, n, pf.f_hz, pf.f2,
+                                                               pf.cX, pf.cY2, h, lane, wc);
                 if (sub == q) my_done = (total != 0.0) ? total + alt_min : qnan();            // :290-292
             }
         }

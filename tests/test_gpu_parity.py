@@ -253,6 +253,27 @@ def test_x_mode_below_the_gyrofrequency_grid_collapses_onto_the_bottom_level(lib
         assert np.array_equal(np.isnan(got0[want0 > 1e-9]), np.isnan(want0[want0 > 1e-9]))
 
 
+@pytest.mark.parametrize("n_points", [200, 2000])
+def test_o_mode_below_the_bottom_plasma_frequency_grid_collapses_onto_the_bottom_level(lib, n_points):
+    """O mode, f below the plasma frequency of the lowest level: X >= 1 there, the same collapsed grid as in X mode
+    below the gyrofrequency - answered without a loop in the default arithmetic (short grids: the four-frequency
+    items; long grids: the per-pair items) and in the reference order."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(48, 778)
+    den = den + np.linspace(1.0e9, 6.0e9, 48)[:, None] * np.exp(-(alt - 80.0) / 400.0)   # f_N(80 km) = 0.28 ... 0.70 MHz
+    freq = np.linspace(0.2, 3.0, 90)
+    want = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", n_points)
+    # (in O mode mu^2 < 0 at X > 1, library.py:233: every term of a collapsed grid is NaN and so is the trace)
+    below_bottom = (freq[None, :] * 1e6) ** 2 < 80.6163849 * den[:, :1]
+    assert (below_bottom & np.isnan(want)).sum() > 50 and np.isfinite(want).sum() > 1000
+    assert not np.isfinite(want[below_bottom]).any()
+    noise = oracle_noise(freq, den, bmag, bpsi, alt, "O", n_points)
+    for math in (None, lib.MATH_FAITHFUL):
+        got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", n_points, math=math)
+        assert_o_mode(got, want, noise)                      # NaN masks identical, values by the noise rule
+
+
 def test_per_profile_altitude_rows(lib):
     g = load_golden("g5_chapman64.npz")
     alt2 = np.tile(g["alt"], (8, 1))
