@@ -42,6 +42,7 @@ long long kTargetWaves = 4096;             // waves resident at two 8-wave workg
 constexpr size_t kPackBytes = 1u << 20;
 int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
 double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
+double kThreadScanMinWork = 1.0e6;        // PRHF_THREAD_SCAN_MIN: n_freq x n_points from which X mode scans per thread
 int kTailGroupMinPoints = 81;             // PRHF_TAIL_GROUP_MIN / _MAX: grids of this many points take four frequencies per item
 int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 of them are ill conditioned: nothing to share)
 int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)
@@ -271,6 +272,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.lean = ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
                   table_is_cheap) ? 1 : 0;
         want_pairs = want_pairs || s.lean != 0;
+        s.thread_scan = ((double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
         plan_slice(s, n_freq, wg_slots);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
@@ -490,6 +492,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
     if (const char* nc = std::getenv("PRHF_NO_CANDIDATES")) kNoCandidates = std::atoi(nc) != 0;
     if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
+    if (const char* ts = std::getenv("PRHF_THREAD_SCAN_MIN")) kThreadScanMinWork = std::atof(ts);
     if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(2, std::atoi(lm));
     if (const char* g0 = std::getenv("PRHF_TAIL_GROUP_MIN")) kTailGroupMinPoints = std::max(81, std::atoi(g0));
     if (const char* g1 = std::getenv("PRHF_TAIL_GROUP_MAX")) kTailGroupMaxPoints = std::atoi(g1);

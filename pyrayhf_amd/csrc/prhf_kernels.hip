@@ -1208,7 +1208,8 @@ __device__ __forceinline__ void prefix_max_in_place(double* v, int K, double* re
 template <int THREADS>
 __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg, const double* keep,
                                                long long pair_base, unsigned short* cand, int* cand_count,
-                                               const Node* nodes, const double* pf2, int K, double* heights) {
+                                               const Node* nodes, const double* pf2, const double* gb, int K,
+                                               double* heights) {
     constexpr int W = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = (int)a.n_freq;
@@ -1220,7 +1221,60 @@ __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg,
         double h = 0.0;
         if (f < F) {
             const double* row = a.ftab + 8 * (long long)f;
-            if (heights) {
+            if (heights && sg.mode == PRHF_KMODE_X) {
+#pragma clang fp contract(off)
+                // X mode: X + Y is not monotone in the level, so every thread scans the levels of its frequency -
+                // with the table's reciprocals, good to 4 ulp, which decides "above 1" and "the largest so far"
+                // for certain outside a band of 1e-13 around 1 and 1e-14 around a tie; the exact quotients
+                // (:136, :157, :389) are then needed at two levels only, the ones np.interp reads.  Inside the
+                // bands the thread repeats the scan with exact divisions.  ~40 vector instructions per pair instead
+                // of ~300 for a wave scanning with two divisions per level (reflection_height).
+                const double f_hz = row[0], f2 = row[1], rf2 = row[4], rf = row[5];
+                int ks = K, km = -1;
+                double m1 = -__builtin_inf(), m2 = -__builtin_inf();
+                bool exact = false;
+                // (a frequency that escapes for certain - the bound of pair_reflects - has nothing to scan)
+                const int K_scan = (pmax * rf2 + gmax * rf < 1.0 - 1e-9) ? 0 : K;
+                for (int k = 0; k < K_scan; ++k) {
+                    const double c = __builtin_fma(pf2[k], rf2, gb[k] * rf);
+                    if (__builtin_fabs(c - 1.0) <= 1e-13) { exact = true; break; }
+                    if (c > 1.0) { ks = k; break; }
+                    if (c > m1) { m2 = m1; m1 = c; km = k; }
+                    else if (c > m2) m2 = c;
+                }
+                if (!exact && km >= 0 && !(m1 - m2 > 1e-14 * __builtin_fabs(m1))) exact = true;
+                double below = -__builtin_inf(), col_star = 0.0;
+                if (K_scan == 0) {
+                    ks = K;                             // below stays -inf: does not reflect
+                } else if (exact) {
+                    ks = K;
+                    for (int k = 0; k < K; ++k) {
+                        const double col = pf2[k] / f2 + gb[k] / f_hz;
+                        if (col > 1.0) { ks = k; col_star = col; break; }
+                        below = fmax(below, col);
+                    }
+                } else {
+                    if (km >= 0) below = pf2[km] / f2 + gb[km] / f_hz;
+                    if (ks < K) col_star = pf2[ks] / f2 + gb[ks] / f_hz;
+                }
+                if (ks == K) {
+                    may = below >= 1.0;                 // == 1 exactly at the top level, else it never reaches the cutoff (:399)
+                    h = nodes[K - 1].alt;
+                } else if (ks == 0) {
+                    may = true;
+                    h = nodes[0].alt;                   // above the cutoff at the bottom already: left clamp
+                } else {
+                    may = true;
+                    const double aj = nodes[ks - 1].alt;
+                    if (below == 1.0) {
+                        h = aj;
+                    } else {
+                        const double slope = (nodes[ks].alt - aj) / (col_star - below);
+                        h = slope * (1.0 - below) + aj;
+                    }
+                }
+                h = h - kBackoff;                       // :407
+            } else if (heights) {
 #pragma clang fp contract(off)
                 // first level whose quotient exceeds 1: fl(p / f2) > 1 <=> p - f2 > f2 2^-53 (see reflection_height)
                 const double f2 = row[1];
@@ -1267,6 +1321,8 @@ __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg,
             if (w < wave) at += n;
             chunk += n;
         }
+        // (X mode keeps its heights where f_N^2 lived: every thread has finished reading that by now - one round,
+        //  n_freq <= THREADS - and the barriers above lie between)
         if (may) {
             const int pos = at + __popcll(mask & ((1ull << lane) - 1ull));
             cand[pos] = (unsigned short)f;
@@ -1596,10 +1652,15 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     info.heights = nullptr;
     if (a.ftab && !a.no_candidates && sg.chunks == 1 && a.n_freq <= PRHF_MAX_CAND && !info.bad && info.K > 1)
     {
-        // (O mode never reads g_p |B| per level again: its array holds the reflection heights)
-        double* heights = (sg.mode == PRHF_KMODE_O && a.n_freq <= a.n_alt) ? gb : nullptr;
+        // Reflection heights settled while the list is made live where the level search kept its input: O mode
+        // never reads g_p |B| per level again; X mode (one round of frequencies only) reads neither array again
+        double* heights = nullptr;
+        if (a.n_freq <= a.n_alt) {
+            if (sg.mode == PRHF_KMODE_O) heights = gb;
+            else if (a.n_freq <= THREADS && sg.thread_scan) heights = pf2;
+        }
         info.n_cand = list_candidates<THREADS>(a, sg, kept_scalars<THREADS>(red), prof_local * a.n_freq, cand,
-                                               cand_count, nodes, pf2, info.K, heights);
+                                               cand_count, nodes, pf2, gb, info.K, heights);
         info.heights = heights;
     }
 #ifdef PRHF_TRACE
