@@ -274,6 +274,30 @@ def test_o_mode_below_the_bottom_plasma_frequency_grid_collapses_onto_the_bottom
         assert_o_mode(got, want, noise)                      # NaN masks identical, values by the noise rule
 
 
+def test_x_mode_heights_per_thread_with_ties_plateaus_and_no_field(lib):
+    """A batch big enough for the prologue's per-thread level scan in X mode (>= 4096 pairs, n_freq x n_points >=
+    1e6): plateaus under a uniform field (exact ties of X + Y between levels: the scan repeats with exact
+    divisions), no field at all, ordinary rows - against the NumPy oracle, and against single-profile launches,
+    which scan per pair."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(40, 4321)
+    bmag[:10] = bmag[:10, :1]                                   # uniform field ...
+    for r in range(10):
+        k = 40 + 7 * r
+        den[r, k:k + 3] = den[r, k]                             # ... and a plateau: equal X + Y at three levels
+    den[5:10, :30] = 0.0                                        # vacuum at the bottom as well
+    bmag[10:20] = 0.0                                           # isotropic rows
+    freq = np.linspace(0.3, 14.0, 128)
+    n_points = 8192
+    want = orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", n_points)
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n_points)
+    assert_x_mode(got, want)
+    for r in (0, 7, 12, 25):
+        one = lib.vertical_forward_operator(freq, den[r], bmag[r], bpsi[r], alt, "X", n_points)
+        assert_x_mode(one, got[r], tol=1e-11)
+
+
 def test_per_profile_altitude_rows(lib):
     g = load_golden("g5_chapman64.npz")
     alt2 = np.tile(g["alt"], (8, 1))
