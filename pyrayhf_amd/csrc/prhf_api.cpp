@@ -42,7 +42,7 @@ long long kTargetWaves = 4096;             // waves resident at two 8-wave workg
 constexpr size_t kPackBytes = 1u << 20;
 int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
 double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
-double kThreadScanMinWork = 1.0e6;        // PRHF_THREAD_SCAN_MIN: n_freq x n_points from which X mode scans per thread
+double kThreadScanMinWork = 0.0;          // PRHF_THREAD_SCAN_MIN: n_freq x n_points from which X mode scans per thread (A/B knob)
 int kTailGroupMinPoints = 81;             // PRHF_TAIL_GROUP_MIN / _MAX: grids of this many points take four frequencies per item
 int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 of them are ill conditioned: nothing to share)
 int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)

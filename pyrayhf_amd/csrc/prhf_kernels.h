@@ -53,8 +53,8 @@ struct SegDev {
     int group;                       // frequencies per work item: 1, or 4 on short grids in the default O-mode
                                      // arithmetic (run_items_tail16: four 16-point tails share one wave-iteration)
     int thread_scan;                 // X mode: reflection heights settled one frequency per thread while the candidate
-                                     // list is made (a serial scan of the levels per thread: worth its latency only
-                                     // where a profile's pairs carry enough work; O mode always does, by binary search)
+                                     // list is made (on by default; PRHF_THREAD_SCAN_MIN turns it off for A/B runs.
+                                     // O mode always does, by binary search)
 };
 
 struct KArgs {

@@ -1227,34 +1227,54 @@ __device__ __forceinline__ int list_candidates(const KArgs& a, const SegDev& sg,
                 // with the table's reciprocals, good to 4 ulp, which decides "above 1" and "the largest so far"
                 // for certain outside a band of 1e-13 around 1 and 1e-14 around a tie; the exact quotients
                 // (:136, :157, :389) are then needed at two levels only, the ones np.interp reads.  Inside the
-                // bands the thread repeats the scan with exact divisions.  ~40 vector instructions per pair instead
-                // of ~300 for a wave scanning with two divisions per level (reflection_height).
+                // bands the thread repeats the scan with exact divisions.  Eight levels per trip, loads in front: the
+                // scan is a chain of LDS round trips in the prologue, and latency there is what it costs.
                 const double f_hz = row[0], f2 = row[1], rf2 = row[4], rf = row[5];
-                int ks = K, km = -1;
+                // The largest value so far is kept as (m1, first level kb of the trip or level that holds it, its
+                // length nb); m2 is the largest value OUTSIDE that stretch: a tie between stretches shows as m1 ~ m2,
+                // a tie inside the best stretch is settled when its levels are evaluated exactly.
+                int ks = K, kb = -1, nb = 0;
                 double m1 = -__builtin_inf(), m2 = -__builtin_inf();
                 bool exact = false;
                 // (a frequency that escapes for certain - the bound of pair_reflects - has nothing to scan)
                 const int K_scan = (pmax * rf2 + gmax * rf < 1.0 - 1e-9) ? 0 : K;
-                for (int k = 0; k < K_scan; ++k) {
+                constexpr int U = 8;                    // levels per trip: sixteen LDS reads in flight, one wait
+                int k = 0;
+                for (; k + U <= K_scan; k += U) {
+                    double c[U];
+#pragma unroll
+                    for (int i = 0; i < U; ++i) c[i] = __builtin_fma(pf2[k + i], rf2, gb[k + i] * rf);
+                    const double g = fmax(fmax(fmax(c[0], c[1]), fmax(c[2], c[3])), fmax(fmax(c[4], c[5]), fmax(c[6], c[7])));
+                    if (g > 1.0 - 1e-13) break;         // the crossing, or a level inside the band: level by level below
+                    const double t = fmin(m1, g);
+                    if (g > m1) { kb = k; nb = U; }
+                    m1 = fmax(m1, g);
+                    m2 = fmax(m2, t);
+                }
+                for (; k < K_scan; ++k) {               // the trip that stopped the loop above, or the last K % U levels
                     const double c = __builtin_fma(pf2[k], rf2, gb[k] * rf);
                     if (__builtin_fabs(c - 1.0) <= 1e-13) { exact = true; break; }
                     if (c > 1.0) { ks = k; break; }
-                    if (c > m1) { m2 = m1; m1 = c; km = k; }
+                    if (c > m1) { m2 = m1; m1 = c; kb = k; nb = 1; }
                     else if (c > m2) m2 = c;
                 }
-                if (!exact && km >= 0 && !(m1 - m2 > 1e-14 * __builtin_fabs(m1))) exact = true;
+                if (!exact && kb >= 0 && !(m1 - m2 > 1e-14 * __builtin_fabs(m1))) exact = true;
                 double below = -__builtin_inf(), col_star = 0.0;
                 if (K_scan == 0) {
                     ks = K;                             // below stays -inf: does not reflect
                 } else if (exact) {
                     ks = K;
-                    for (int k = 0; k < K; ++k) {
-                        const double col = pf2[k] / f2 + gb[k] / f_hz;
-                        if (col > 1.0) { ks = k; col_star = col; break; }
+                    for (int kk = 0; kk < K; ++kk) {
+                        const double col = pf2[kk] / f2 + gb[kk] / f_hz;
+                        if (col > 1.0) { ks = kk; col_star = col; break; }
                         below = fmax(below, col);
                     }
                 } else {
-                    if (km >= 0) below = pf2[km] / f2 + gb[km] / f_hz;
+                    // exact quotients of the best stretch's levels that can hold the exact maximum
+                    for (int i = 0; i < nb; ++i) {
+                        const double c = __builtin_fma(pf2[kb + i], rf2, gb[kb + i] * rf);
+                        if (c >= m1 - 4e-15 * __builtin_fabs(m1)) below = fmax(below, pf2[kb + i] / f2 + gb[kb + i] / f_hz);
+                    }
                     if (ks < K) col_star = pf2[ks] / f2 + gb[ks] / f_hz;
                 }
                 if (ks == K) {
