@@ -22,6 +22,9 @@
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 96          // one staged bottomside level
 #define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
+#ifndef PRHF_TOP_MIN_POINTS
+#define PRHF_TOP_MIN_POINTS 1024    // grids from this many points on give their top segment a loop of its own
+#endif
 #ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
 #endif

@@ -898,7 +898,7 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     TopSegment top;
     __builtin_memset(&top, 0, sizeof top);
     bool top_phase = false;
-    if (TOP && !HINT && end - first >= 1024) {
+    if (TOP && !HINT && end - first >= PRHF_TOP_MIN_POINTS) {
         const int i_last = (last_special >= 0 ? last_special : end - 1);
         const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, i_last * (int)sizeof(double2), 0);
         double2 gl;
@@ -1098,7 +1098,7 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             if (by_hint) r = PRHF_LEAN_POLY(true, false);
             // (a chunk of a pair keeps to the indexed steps: the search for the top segment's first point costs
             // three dependent loads, which a latency-bound chunked launch cannot hide and every chunk would repeat)
-            else if (lean_end - first >= 1024 && i0 == 0 && to_grid_end) r = PRHF_LEAN_POLY(false, true);
+            else if (lean_end - first >= PRHF_TOP_MIN_POINTS && i0 == 0 && to_grid_end) r = PRHF_LEAN_POLY(false, true);
             else r = PRHF_LEAN_POLY(false, false);
 #undef PRHF_LEAN_POLY
 #undef PRHF_LEAN
