@@ -856,10 +856,10 @@ struct LeanResult {
 // TOP: with the top-segment phase (long grids on a uniform altitude grid); the short-grid callers use the
 // variant without it, which needs 24 fewer vector registers around the call.
 template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
-__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds,
-                                                          const double2* __restrict__ pairs, int first, int end,
-                                                          int last_special, double span, double a0, double kj,
-                                                          double cX, double cY2, double well_conditioned) {
+__device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigned hint_lds,
+                                                     const double2* __restrict__ pairs, int first, int end,
+                                                     int last_special, double span, double a0, double kj,
+                                                     double cX, double cY2, double well_conditioned) {
 #pragma clang fp contract(fast)
     // arguments arrive in VGPRs: back to SGPRs.  The node table travels as its 32-bit LDS address (a
     // generic pointer would turn every node read into a flat load).
@@ -1044,6 +1044,65 @@ __device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, un
     r.acc = accm * span;                               // :415: dh = (m_i+1 - m_i) * span
     r.first = first;
     return r;
+}
+
+// The checked main loop for the short grids of run_items_tail16: grid points [0, end) of one pair, end <= 1000,
+// inlined into the item loop.  On a 200-point grid a pair has three wave-iterations of points, and the call of
+// lean_loop - arguments through vector registers and back into scalars, the dynamic-LDS base from its table, the
+// two-iterations-per-trip control flow - was a quarter of what the pair cost.  One wave-iteration per trip, the next
+// trip's grid entries loaded in front; every argument is wave-uniform already.  Same arithmetic, same stop rule
+// (in front of the first point with 1 - X <= wc) as lean_loop<MODE, true, POLY, HINT, false>.
+template <int MODE, int POLY, bool HINT>
+__device__ __forceinline__ LeanResult lean_checked_short(unsigned nodes_lds, unsigned hint_lds,
+                                                         const double2* __restrict__ pairs, int end, double span,
+                                                         double a0, double kj, double cX, double cY2, double wc) {
+#pragma clang fp contract(fast)
+    const int lane = threadIdx.x & 63;
+    const double hcY2 = uniform(0.5 * cY2);
+    double a0v = a0;
+    unsigned nodes_v = nodes_lds, hint_v = hint_lds;
+    asm volatile("" : "+v"(a0v), "+v"(nodes_v), "+v"(hint_v));
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double2*>(pairs), 0, 0x7fffffff, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto grid_at = [&](int i) {                    // entries past `end` are read (the table is padded) and not used
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
+        double2 g;
+        __builtin_memcpy(&g, &v, sizeof g);
+        return g;
+    };
+    double acc = 0.0;
+    unsigned long long viol = 0;
+    int first = 0;
+    double2 g = grid_at(0);
+    while (first < end) {
+        const double2 gn = grid_at(first + 64);
+        if (first + lane >= end) g = make_double2(0.0, 0.0);       // an idle lane re-evaluates grid point 0 with weight 0
+        const double a1 = lean_step<MODE, true, POLY, HINT>(g, span, a0v, kj, cX, hcY2, acc, wc, viol, nodes_v, hint_v);
+        if (viol) {
+            const int L = __ffsll((long long)viol) - 1;
+            if (lane < L) acc = a1;
+            first += L;
+            break;
+        }
+        acc = a1;
+        first = min(first + 64, end);
+        g = gn;
+    }
+    LeanResult r;
+    r.acc = acc * span;
+    r.first = first;
+    return r;
+}
+
+template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
+__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds,
+                                                          const double2* __restrict__ pairs, int first, int end,
+                                                          int last_special, double span, double a0, double kj,
+                                                          double cX, double cY2, double well_conditioned) {
+    return lean_loop_body<MODE, CHECK, POLY, HINT, TOP>(nodes_lds, hint_lds, pairs, first, end, last_special, span, a0, kj,
+                                                         cX, cY2, well_conditioned);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1533,6 +1592,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 // starts above cutoff) goes through the general path by itself.  Values do not depend on which pairs
 // share an iteration: the tail is always evaluated in the reference's order, point by point.
 constexpr int kTail = 16;
+// (-DPRHF_TAIL_LEAN=lean_loop or =lean_loop_body: the general loop, called or inlined, instead of lean_checked_short - A/B)
 template <int MODE, int THREADS>
 __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& sg, const Node* nodes,
                                                  const double* pf2, const double* gb,
@@ -1589,8 +1649,12 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
             bool shared = false;
             if (span > 0.0 && in_table) {
                 LeanResult r;
-#define PRHF_LEAN(P, H) lean_loop<MODE, true, P, H, false>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
+#ifdef PRHF_TAIL_LEAN
+#define PRHF_LEAN(P, H) PRHF_TAIL_LEAN<MODE, true, P, H, false>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
                                                              pf.cX, pf.cY2, wc)
+#else
+#define PRHF_LEAN(P, H) lean_checked_short<MODE, P, H>(nodes_lds, hint_lds, pairs, n - kTail, span, a0, kj, pf.cX, pf.cY2, wc)
+#endif
                 if (by_hint) r = poly == 1 ? PRHF_LEAN(1, true) : (poly == 2 ? PRHF_LEAN(2, true) : PRHF_LEAN(3, true));
                 else r = poly == 1 ? PRHF_LEAN(1, false) : (poly == 2 ? PRHF_LEAN(2, false) : PRHF_LEAN(3, false));
 #undef PRHF_LEAN
