@@ -365,7 +365,7 @@ struct BlockInfo {
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
-    int poly_angle;   // every segment has a sin^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too); 0: some use sin()
+    int poly_angle;   // every segment has a 2 cos^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too); 0: some use sin()
     int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
     const double* heights;   // O mode with a candidate list: reflection height of every entry (they all reflect); else null
     double a0;        // alt[0]
@@ -732,7 +732,7 @@ __device__ __forceinline__ double group_index_lean(double den, double hY2, doubl
 // D > 0, q = X(1-X)/D >= 0, so the mu > 1 cliff (:238) cannot trigger.
 // CHECK: also report (in `viol`, a lane mask) the points whose 1 - X is not above `wc` - the default O-mode
 // arithmetic only accepts wave-iterations where the reduced algebra is safe.
-// POLY: degree of the sin^2 psi polynomial every segment of the profile carries: 3 cubic, 2 economised
+// POLY: degree of the 2 cos^2 psi polynomial every segment of the profile carries: 3 cubic, 2 economised
 // quadratic (u3 = 0, not read), 1 economised linear (u2 = 0 too, not read).
 // HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
@@ -798,8 +798,8 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
 // The top segment of a pair in m: about half of a long grid's points lie between the last level below the
 // reflection height and the reflection height itself (the stretched grid is dense there).  For those points the
 // node is the same for every lane and every trip, so the three interpolants become polynomials in m with
-// wave-uniform coefficients - no segment index, no LDS read, no abscissa, Y straight from m: 35 instructions
-// per point instead of 40 (34 against 39 with the linear sin^2 psi).
+// wave-uniform coefficients - no segment index, no LDS read, no abscissa, Y straight from m: 32 instructions
+// per point instead of 37 (with the linear angle polynomial; 34 against 39 with the cubic).
 struct TopSegment {
     double d0, d1;          // den  = d0 + d1 m
     double b0, b1;          // Y / sqrt(2) = g_p |B| / (sqrt(2) f) = b0 + b1 m
@@ -1623,7 +1623,7 @@ __device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& s
     typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
     const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
     const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
-    const int poly = 4 - info.poly_angle;              // degree of the sin^2 psi polynomials: 3, 2 or 1
+    const int poly = 4 - info.poly_angle;              // degree of the angle polynomials: 3, 2 or 1
     const double alt_min = keep[kKeepAltMin];
     const int ti = n - kTail + (lane & 15);        // this lane's tail point
     for (int t = next_item(); t < T; t = next_item()) {
