@@ -1934,15 +1934,14 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
     const bool wide = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(psi) |
                         reinterpret_cast<uintptr_t>(mu_out) | reinterpret_cast<uintptr_t>(mup_out)) & 15) == 0;
     const long long n2 = wide ? n >> 1 : 0;
-    const double2* X2 = reinterpret_cast<const double2*>(X);
-    const double2* Y2 = reinterpret_cast<const double2*>(Y);
-    const double2* P2 = reinterpret_cast<const double2*>(psi);
     for (long long i = tid; i < n2; i += stride) {
-        const double2 x = X2[i], y = Y2[i], ps = P2[i];
+        typedef double vec2 __attribute__((ext_vector_type(2)));
+        // (plain loads, streaming stores: non-temporal loads measured no better)
+        const vec2 x = reinterpret_cast<const vec2*>(X)[i], y = reinterpret_cast<const vec2*>(Y)[i];
+        const vec2 ps = reinterpret_cast<const vec2*>(psi)[i];
         double mu0, mup0, mu1, mup1;
         one(x.x, y.x, ps.x, &mu0, &mup0);
         one(x.y, y.y, ps.y, &mu1, &mup1);
-        typedef double vec2 __attribute__((ext_vector_type(2)));
         const vec2 m = {mu0, mu1}, mp = {mup0, mup1};
         __builtin_nontemporal_store(m, reinterpret_cast<vec2*>(mu_out) + i);
         __builtin_nontemporal_store(mp, reinterpret_cast<vec2*>(mup_out) + i);
@@ -2145,20 +2144,21 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
             b = nd.sb * dz + nd.b;
             p = nd.spsi * dz + nd.psi;
         }
-        a.out_freq[row + i] = f_hz;
-        a.out_den[row + i] = d;
-        a.out_bmag[row + i] = b;
-        a.out_bpsi[row + i] = p;
-        a.out_dist[row + i] = dh;
-        a.out_alt[row + i] = z;
-        a.out_crit[row + i] = h;
-        a.out_ind[row + i] = i;
+        // (written once, never read back here: streaming stores)
+        __builtin_nontemporal_store(f_hz, a.out_freq + row + i);
+        __builtin_nontemporal_store(d, a.out_den + row + i);
+        __builtin_nontemporal_store(b, a.out_bmag + row + i);
+        __builtin_nontemporal_store(p, a.out_bpsi + row + i);
+        __builtin_nontemporal_store(dh, a.out_dist + row + i);
+        __builtin_nontemporal_store(z, a.out_alt + row + i);
+        __builtin_nontemporal_store(h, a.out_crit + row + i);
+        __builtin_nontemporal_store((long long)i, a.out_ind + row + i);
     }
 }
 
 hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream) {
     if (a.n_freq <= 0 || a.n_points <= 0) return hipSuccess;
-    hipLaunchKernelGGL(regrid_kernel<256>, dim3((unsigned)a.n_freq), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL(regrid_kernel<512>, dim3((unsigned)a.n_freq), dim3(512), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -2222,7 +2222,7 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
     const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
-                             reinterpret_cast<const void*>(&regrid_kernel<256>)};
+                             reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
         if (e != hipSuccess) return e;
