@@ -362,6 +362,11 @@ def test_mixed_worklist_on_device_tensors(lib):
     assert out.is_cuda and out.shape == (24, g["freq"].size)
     assert np.array_equal(out.cpu().numpy(), host, equal_nan=True)
     assert np.all(np.isnan(host[14:20]))
+    # sync=False: enqueued on torch's current stream; a torch op behind it sees the finished rows
+    late = lib.vertical_forward_operator_mixed(*t, segs, sync=False)
+    doubled = late * 2.0
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(doubled.cpu().numpy(), host * 2.0, equal_nan=True)
 
 
 def test_cached_device_grids_alternate_without_going_stale(lib):
