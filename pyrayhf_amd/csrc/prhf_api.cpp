@@ -288,6 +288,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     for (int i = 0; i < n_segs; ++i) {
         prhf::SegDev& s = a.seg[i];
         const long long P = s.prof_end - s.prof_begin;
+        s.prio = std::max(0, 3 - i);               // (sorted: the slice with the longest workgroups first)
         s.block_begin = blocks;
         blocks += s.tail_prof * s.blocks_per_prof + (P - s.tail_prof) * s.tail_bpp;
         if (s.chunks > 1) {

@@ -55,6 +55,7 @@ struct SegDev {
                                      // slice gets the same arithmetic alone and inside a mixed launch
     int group;                       // frequencies per work item: 1, or 4 on short grids in the default O-mode
                                      // arithmetic (run_items_tail16: four 16-point tails share one wave-iteration)
+    int prio;                        // wave priority (0..3) of this slice's workgroups in a mixed launch: see vfo_kernel
     int thread_scan;                 // X mode: reflection heights settled one frequency per thread while the candidate
                                      // list is made (on by default; PRHF_THREAD_SCAN_MIN turns it off for A/B runs.
                                      // O mode always does, by binary search)

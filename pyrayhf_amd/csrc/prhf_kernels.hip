@@ -1813,6 +1813,22 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         }
         const long long prof_local = prof0 + lb / bpp;
         const int block_in_prof = (int)(lb % bpp);
+        // Mixed launches: a slice's workgroups run at a wave priority that falls with their length.  The SIMD arbiter
+        // prefers its older waves, and in a persistent launch the workgroup that arrived first on a CU stays the older
+        // one for ever: its neighbour's waves get the issue slots it leaves.  With equal work per block that only shifts
+        // time between the two; in a mixed list (longest blocks first) the neighbour's long first block was still
+        // running when everything else was done - config 5: the 20000-point blocks of the CUs' second workgroups took
+        // 4 - 9 ms against 1 - 4 ms for the first ones, and the launch ended on them with 2 - 250 of 512 slots busy
+        // for its last sixth (tools/wave_trace5.py).  A long block now outranks the shorter ones that the other
+        // workgroup pulls after its own.
+        // (Homogeneous launches: raising a block's priority when its second half begins evened out the lives - the
+        // longest fell from 12 to 9.6 ms at 20000 points - and left the launch time where it was.)
+        if (a.n_segs > 1) {
+            if (sg.prio >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (sg.prio == 2) __builtin_amdgcn_s_setprio(2);
+            else if (sg.prio == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 
         const unsigned long long t_staged = (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
             ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
