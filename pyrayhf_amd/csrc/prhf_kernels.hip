@@ -1823,10 +1823,18 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         // workgroup pulls after its own.
         // (Homogeneous launches: raising a block's priority when its second half begins evened out the lives - the
         // longest fell from 12 to 9.6 ms at 20000 points - and left the launch time where it was.)
-        if (a.n_segs > 1) {
-            if (sg.prio >= 3) __builtin_amdgcn_s_setprio(3);
-            else if (sg.prio == 2) __builtin_amdgcn_s_setprio(2);
-            else if (sg.prio == 1) __builtin_amdgcn_s_setprio(1);
+        int prio = sg.prio;
+        if (a.n_segs == 1 && a.queue != nullptr) {
+            // one slice: the blocks of the last three resident rounds rank below everything pulled before them, round
+            // by round, so that the launch ends on its newest (and, in the last round, quartered) blocks and not on
+            // an old one that its neighbour kept waiting
+            const long long left = a.n_blocks - bid, round = gridDim.x;
+            prio = left > 3 * round ? 3 : (left > 2 * round ? 2 : (left > round ? 1 : 0));
+        }
+        if (a.n_segs > 1 || a.queue != nullptr) {
+            if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
 
