@@ -1977,9 +1977,16 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
         mup_out[i] = mup;
     }
     if (track) {
+        // one pair of atomics per workgroup: they all hit the same two words, ~12 ns each, one after the other
+        __shared__ double wg_max[4];
+        __shared__ int wg_seen[4];
         ymax = wave_max(ymax);
         seen = __any(seen) ? 1 : 0;
-        if ((threadIdx.x & 63) == 0) {             // (a few thousand waves: the two atomics per wave do not show)
+        if ((threadIdx.x & 63) == 0) { wg_max[threadIdx.x >> 6] = ymax; wg_seen[threadIdx.x >> 6] = seen; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int waves = (int)(blockDim.x >> 6);
+            for (int w = 1; w < waves; ++w) { ymax = fmax(ymax, wg_max[w]); seen |= wg_seen[w]; }
             atomicMax(track, (unsigned long long)__double_as_longlong(ymax));
             if (seen) atomicOr(track + 1, 1ull);
         }
@@ -2051,9 +2058,8 @@ __global__ void find_vh_kernel(const double* __restrict__ X, const double* __res
     const long long base = row * n_cols;
     double acc = 0.0, ymax = 0.0;
     int seen = 0;
-    for (long long i = lane; i < n_cols; i += 64) {
+    auto one = [&](double x, double y, double p, double thickness) {
         double mu, mup;
-        const double x = X[base + i], y = Y[base + i], p = psi[base + i];
         const double ay = fabs(y);
         ymax = fmax(ymax, ay);                                 // the isotropic test of :201, same pass (mu_mup_kernel)
         seen |= (ay == ay) ? 1 : 0;
@@ -2067,8 +2073,26 @@ __global__ void find_vh_kernel(const double* __restrict__ X, const double* __res
             if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, sn * sn, &mu, &mup);
             else index_fast<PRHF_KMODE_X>(x, y * y, sn * sn, &mu, &mup);
         }
-        const double term = mup * dh[base + i];            // :288
+        const double term = mup * thickness;                   // :288
         if (term == term) acc = acc + term;
+    };
+    // two columns per lane and trip where the row starts on a 16-byte boundary in all four arrays
+    const bool wide = (n_cols & 1) == 0 &&
+        ((reinterpret_cast<uintptr_t>(X + base) | reinterpret_cast<uintptr_t>(Y + base) |
+          reinterpret_cast<uintptr_t>(psi + base) | reinterpret_cast<uintptr_t>(dh + base)) & 15) == 0;
+    if (wide) {
+        typedef double vec2 __attribute__((ext_vector_type(2)));
+        const vec2* X2 = reinterpret_cast<const vec2*>(X + base);
+        const vec2* Y2 = reinterpret_cast<const vec2*>(Y + base);
+        const vec2* P2 = reinterpret_cast<const vec2*>(psi + base);
+        const vec2* D2 = reinterpret_cast<const vec2*>(dh + base);
+        for (long long i = lane; i < (n_cols >> 1); i += 64) {
+            const vec2 x = X2[i], y = Y2[i], p = P2[i], d = D2[i];
+            one(x.x, y.x, p.x, d.x);
+            one(x.y, y.y, p.y, d.y);
+        }
+    } else {
+        for (long long i = lane; i < n_cols; i += 64) one(X[base + i], Y[base + i], psi[base + i], dh[base + i]);
     }
     acc = wave_sum(acc);
     if (lane == 0) vh[row] = (acc != 0.0) ? acc + alt_min : qnan();     // :290-292
