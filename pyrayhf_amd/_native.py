@@ -18,7 +18,7 @@ OK, EINVAL, ENEGDEN, EPEAK0, EHIP, ENOMEM = 0, -1, -2, -3, -4, -5
 MODE_O, MODE_X = 0, 1
 FLAG_DEVICE_PTRS, FLAG_ASYNC, FLAG_GRID_STABLE = 0x1, 0x2, 0x4
 MATH_FAITHFUL, MATH_FAST, MATH_AUTO = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 
