@@ -1,0 +1,17 @@
+"""Latency of the drop-in call as a PyRayHF user makes it: NumPy arrays in, NumPy array out, one profile."""
+import sys, os, json, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from pyrayhf_amd import library, synth
+alt, den, bmag, bpsi = synth.chapman_profiles(4, 99)
+freq = synth.sounder_frequencies(1)
+for mode, n in (("O", 200), ("X", 200), ("O", 2000), ("X", 20000)):
+    for _ in range(5):
+        library.vertical_forward_operator(freq, den[0], bmag[0], bpsi[0], alt, mode, n)
+    t0 = time.perf_counter()
+    reps = 200
+    for _ in range(reps):
+        vh = library.vertical_forward_operator(freq, den[0], bmag[0], bpsi[0], alt, mode, n)
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"call": f"vertical_forward_operator(174 freqs, 1 profile, '{mode}', {n}) on NumPy arrays", "us_per_call": 1e6 * dt,
+                      "kernel_us": 1e3 * library.last_kernel_ms(), "finite": int(np.isfinite(vh).sum())}), flush=True)

@@ -27,3 +27,7 @@ print(json.dumps({"blocks": int(w.shape[0]), "kernel_us": float(end.max()),
                   "item_loop_us": {"mean": float(items.mean())},
                   "wave_slot_fill_in_item_loop": float(((end - staged).sum()) / (8 * items.sum())),
                   "sum_of_block_lives_over_kernel_x_slots": float(life.sum() / (end.max() * 512))}))
+wg_start, wg_end = start.min(axis=1), end.max(axis=1)
+edges = np.linspace(0, wg_end.max(), 41)
+print("resident workgroups per 1/40 of the launch:", [round((np.minimum(wg_end, b) - np.maximum(wg_start, a)).clip(0).sum() / (b - a)) for a, b in zip(edges[:-1], edges[1:])])
+print("busy waves per 1/40 of the launch:", [round((np.minimum(end, b) - np.maximum(start, a)).clip(0).sum() / (b - a)) for a, b in zip(edges[:-1], edges[1:])])
