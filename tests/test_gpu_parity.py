@@ -298,6 +298,20 @@ def test_x_mode_heights_per_thread_with_ties_plateaus_and_no_field(lib):
         assert_x_mode(one, got[r], tol=1e-11)
 
 
+def test_between_512_and_1024_frequencies(lib):
+    """A candidate list exists (<= 1024 frequencies, >= 4096 pairs) but X mode has no room for per-thread heights
+    (more frequencies than threads): O mode settles its heights in the prologue, X mode scans per pair."""
+    from oracle import vfo_numpy as orc
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(8, 606)
+    freq = np.linspace(0.3, 15.0, 600)
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 300)
+    assert_x_mode(got, orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", 300))
+    got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", 200)
+    assert_o_mode(got, orc.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", 200),
+                  oracle_noise(freq, den, bmag, bpsi, alt, "O", 200))
+
+
 def test_per_profile_altitude_rows(lib):
     g = load_golden("g5_chapman64.npz")
     alt2 = np.tile(g["alt"], (8, 1))
