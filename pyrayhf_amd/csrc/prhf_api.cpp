@@ -48,6 +48,7 @@ int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 o
 int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
+int kSplitFewProfiles = 1;                 // PRHF_SPLIT_FEW_PROFILES=0: one workgroup per profile whatever their number
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
@@ -166,6 +167,15 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
                                                                  std::max<long long>(P, 1)));
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    // A long slice with few profiles - fewer than four resident rounds of one-workgroup profiles - is a launch of one
+    // or two rounds whose last one is mostly empty slots (625 profiles of 20000 points on 512 slots: 7.8 ms for
+    // 4.4 ms of work, tools/slice_cost5.py).  Cut every profile of such a slice into up to eight workgroups, each
+    // with its share of the frequencies (it stages the profile again: ~13 us against milliseconds of items).
+    if (kSplitFewProfiles && s.blocks_per_prof == 1 && chunks == 1 && N >= 1024 && P > 0 && P < 4 * wg_slots) {
+        long long bpp = std::min<long long>(8, (4 * wg_slots + P - 1) / P);
+        while (bpp > 1 && items < bpp * kWavesPerBlock * 2) --bpp;     // at least two items per wave
+        s.blocks_per_prof = (int)bpp;
+    }
     // A long slice of one-workgroup profiles ends on whole workgroups (milliseconds each at n_points = 20000)
     // while most of the chip has already drained.  Cut the profiles of the last kTailRounds rounds of
     // workgroup slots into kTailBpp workgroups each: the launch then drains in a fraction of a workgroup time.
@@ -498,6 +508,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* g0 = std::getenv("PRHF_TAIL_GROUP_MIN")) kTailGroupMinPoints = std::max(81, std::atoi(g0));
     if (const char* g1 = std::getenv("PRHF_TAIL_GROUP_MAX")) kTailGroupMaxPoints = std::atoi(g1);
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
+    if (const char* sf = std::getenv("PRHF_SPLIT_FEW_PROFILES")) kSplitFewProfiles = std::atoi(sf);
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;
     int n = 0;
