@@ -169,12 +169,12 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     // A long slice with few profiles - fewer than four resident rounds of one-workgroup profiles - is a launch of one
     // or two rounds whose last one is mostly empty slots (625 profiles of 20000 points on 512 slots: 7.8 ms for
-    // 4.4 ms of work, tools/slice_cost5.py).  Cut every profile of such a slice into up to eight workgroups, each
+    // 4.4 ms of work, tools/slice_cost5.py).  Cut every profile of such a slice into several workgroups (up to 32), each
     // with its share of the frequencies (it stages the profile again: ~13 us against milliseconds of items).
-    if (kSplitFewProfiles && s.blocks_per_prof == 1 && chunks == 1 && N >= 1024 && P > 0 && P < 4 * wg_slots) {
-        long long bpp = std::min<long long>(8, (4 * wg_slots + P - 1) / P);
+    if (kSplitFewProfiles && chunks == 1 && N >= 1024 && P > 0 && P * s.blocks_per_prof < 4 * wg_slots) {
+        long long bpp = std::min<long long>(32, (4 * wg_slots + P - 1) / P);
         while (bpp > 1 && items < bpp * kWavesPerBlock * 2) --bpp;     // at least two items per wave
-        s.blocks_per_prof = (int)bpp;
+        if (bpp > s.blocks_per_prof) s.blocks_per_prof = (int)bpp;
     }
     // A long slice of one-workgroup profiles ends on whole workgroups (milliseconds each at n_points = 20000)
     // while most of the chip has already drained.  Cut the profiles of the last kTailRounds rounds of
