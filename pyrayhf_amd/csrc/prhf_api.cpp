@@ -48,6 +48,7 @@ int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 o
 int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)
 int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
 double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
+int kSplitMinPoints = 1024;                // PRHF_SPLIT_MIN_POINTS
 int kSplitFewProfiles = 1;                 // PRHF_SPLIT_FEW_PROFILES=0: one workgroup per profile whatever their number
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
@@ -171,7 +172,7 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     // or two rounds whose last one is mostly empty slots (625 profiles of 20000 points on 512 slots: 7.8 ms for
     // 4.4 ms of work, tools/slice_cost5.py).  Cut every profile of such a slice into several workgroups (up to 32), each
     // with its share of the frequencies (it stages the profile again: ~13 us against milliseconds of items).
-    if (kSplitFewProfiles && chunks == 1 && N >= 1024 && P > 0 && P * s.blocks_per_prof < 4 * wg_slots) {
+    if (kSplitFewProfiles && chunks == 1 && N >= kSplitMinPoints && P > 0 && P * s.blocks_per_prof < 4 * wg_slots) {
         long long bpp = std::min<long long>(32, (4 * wg_slots + P - 1) / P);
         while (bpp > 1 && items < bpp * kWavesPerBlock * 2) --bpp;     // at least two items per wave
         if (bpp > s.blocks_per_prof) s.blocks_per_prof = (int)bpp;
@@ -509,6 +510,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* g1 = std::getenv("PRHF_TAIL_GROUP_MAX")) kTailGroupMaxPoints = std::atoi(g1);
     if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
     if (const char* sf = std::getenv("PRHF_SPLIT_FEW_PROFILES")) kSplitFewProfiles = std::atoi(sf);
+    if (const char* sm = std::getenv("PRHF_SPLIT_MIN_POINTS")) kSplitMinPoints = std::atoi(sm);
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     *out = nullptr;
     int n = 0;
