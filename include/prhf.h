@@ -52,12 +52,15 @@ extern "C" {
 #define PRHF_FLAG_GRID_STABLE 0x4u  /* device pointers only: the multiplier array at this address keeps its contents
                                      * for as long as the context lives, so the table the library derives from it
                                      * (grid steps, one small kernel) is built once per (address, length) and reused */
+#define PRHF_FLAG_SHARED_FIELD 0x8u /* bmag and bpsi are ONE row of n_alt values each, shared by every profile (a fit's
+                                     * candidates differ in their density only, library.py:589-591): a third of the
+                                     * bytes to upload and to read */
 
 /* arithmetic tiers, prhf_ctx_set_math (see DESIGN.md "Arithmetic tiers") */
 #define PRHF_MATH_FAITHFUL 0  /* reference operation order, IEEE divide/sqrt, no contraction */
 #define PRHF_MATH_FAST     1  /* reduced algebra, rsqrt + Newton, contracted; X-mode error <= 1e-9 relative */
 #define PRHF_MATH_AUTO     2  /* the default, per slice.  X mode: fast.  O mode (ill conditioned near X = 1): the
-                               * reference's operation order at every grid point with 1 - X <= 1e-4, the reduced
+                               * reference's operation order at every grid point with 1 - X <= 1e-5, the reduced
                                * algebra where the order cannot matter; reproduces the reference to 1e-10 */
 
 typedef struct prhf_ctx prhf_ctx;

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PRHF_LIB") or os.path.join(_HERE, "libprhf.so")   # P
 
 OK, EINVAL, ENEGDEN, EPEAK0, EHIP, ENOMEM = 0, -1, -2, -3, -4, -5
 MODE_O, MODE_X = 0, 1
-FLAG_DEVICE_PTRS, FLAG_ASYNC, FLAG_GRID_STABLE = 0x1, 0x2, 0x4
+FLAG_DEVICE_PTRS, FLAG_ASYNC, FLAG_GRID_STABLE, FLAG_SHARED_FIELD = 0x1, 0x2, 0x4, 0x8
 MATH_FAITHFUL, MATH_FAST, MATH_AUTO = 0, 1, 2
 ABI_VERSION = 2
 

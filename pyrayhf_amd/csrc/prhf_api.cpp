@@ -222,9 +222,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         return fail(PRHF_EINVAL, "row stride shorter than a row");
     if (n_segs < 1 || n_segs > PRHF_MAX_SEGMENTS)
         return fail(PRHF_EINVAL, "1..%d segments per launch", PRHF_MAX_SEGMENTS);
-    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE))
+    if (flags & ~(PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE | PRHF_FLAG_SHARED_FIELD))
         return fail(PRHF_EINVAL, "unknown flag bits");
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
+    const bool shared_field = (flags & PRHF_FLAG_SHARED_FIELD) != 0;
     if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
         return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
     // Host buffers: a sounder frequency must be a positive finite number (the reference divides by it and returns
@@ -325,19 +326,21 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         a.freq = freq; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = mult;
         a.out = out;
         a.prof_stride = prof_stride;
+        a.field_stride = shared_field ? 0 : prof_stride;
         a.alt_stride = alt_stride;
     } else {
         const size_t n_alt_rows = alt_stride ? (size_t)n_prof : 1;
+        const size_t n_field_rows = shared_field ? 1 : (size_t)n_prof;
         const size_t post_elems = post ? (size_t)n_freq + out_elems + (size_t)n_prof : 0;
-        const size_t elems = (size_t)n_freq + 3 * (size_t)n_prof * n_alt + n_alt_rows * n_alt +
+        const size_t elems = (size_t)n_freq + ((size_t)n_prof + 2 * n_field_rows) * n_alt + n_alt_rows * n_alt +
                              (size_t)mult_len + out_elems + post_elems;
         if ((rc = ensure(c, c->arena, elems * 8)) != PRHF_OK) return rc;
         double* base = static_cast<double*>(c->arena.p);
         double* d_freq = base;
         double* d_den = d_freq + n_freq;
         double* d_bmag = d_den + (size_t)n_prof * n_alt;
-        double* d_bpsi = d_bmag + (size_t)n_prof * n_alt;
-        double* d_alt = d_bpsi + (size_t)n_prof * n_alt;
+        double* d_bpsi = d_bmag + n_field_rows * n_alt;
+        double* d_alt = d_bpsi + n_field_rows * n_alt;
         double* d_mult = d_alt + n_alt_rows * n_alt;
         d_out = d_mult + mult_len;
         const size_t in_elems = (size_t)(d_out - base);
@@ -351,8 +354,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             std::memcpy(h + (d_freq - base), freq, (size_t)n_freq * 8);
             for (int64_t p = 0; p < n_prof; ++p) {
                 std::memcpy(h + (d_den - base) + (size_t)p * n_alt, den + (size_t)p * prof_stride, row_bytes);
-                std::memcpy(h + (d_bmag - base) + (size_t)p * n_alt, bmag + (size_t)p * prof_stride, row_bytes);
-                std::memcpy(h + (d_bpsi - base) + (size_t)p * n_alt, bpsi + (size_t)p * prof_stride, row_bytes);
+                if (!shared_field || p == 0) {
+                    std::memcpy(h + (d_bmag - base) + (size_t)p * n_alt, bmag + (size_t)p * prof_stride, row_bytes);
+                    std::memcpy(h + (d_bpsi - base) + (size_t)p * n_alt, bpsi + (size_t)p * prof_stride, row_bytes);
+                }
                 if (alt_stride) std::memcpy(h + (d_alt - base) + (size_t)p * n_alt, alt + (size_t)p * alt_stride, row_bytes);
             }
             if (!alt_stride) std::memcpy(h + (d_alt - base), alt, row_bytes);
@@ -364,9 +369,9 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             if (n_prof > 0) {
                 HIP_TRY(hipMemcpy2DAsync(d_den, row_bytes, den, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
                                          hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(hipMemcpy2DAsync(d_bmag, row_bytes, bmag, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                HIP_TRY(hipMemcpy2DAsync(d_bmag, row_bytes, bmag, (size_t)prof_stride * 8, row_bytes, n_field_rows,
                                          hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(hipMemcpy2DAsync(d_bpsi, row_bytes, bpsi, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
+                HIP_TRY(hipMemcpy2DAsync(d_bpsi, row_bytes, bpsi, (size_t)prof_stride * 8, row_bytes, n_field_rows,
                                          hipMemcpyHostToDevice, c->stream));
             }
             if (alt_stride) {
@@ -384,6 +389,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         for (int i = 0; i < n_segs; ++i) covered += segs[i].prof_end - segs[i].prof_begin;
         if (covered < out_rows && out_elems) HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_elems * 8, c->stream));
         a.prof_stride = n_alt;
+        a.field_stride = shared_field ? 0 : n_alt;
         a.alt_stride = alt_stride ? n_alt : 0;
     }
 

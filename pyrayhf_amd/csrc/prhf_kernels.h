@@ -78,6 +78,7 @@ struct KArgs {
     long long n_blocks;              // blocks of work in this launch
     unsigned long long* trace;       // -DPRHF_TRACE builds: (start, end) wall clock of every wave, else unused
     long long n_freq, n_alt, prof_stride, alt_stride;
+    long long field_stride;          // row stride of bmag and bpsi: prof_stride, or 0 when one row serves every profile
     int n_segs;
     int no_candidates;               // PRHF_NO_CANDIDATES=1 (A/B runs): every frequency is a work item, none is pre-filtered
     SegDev seg[PRHF_MAX_SEGMENTS];

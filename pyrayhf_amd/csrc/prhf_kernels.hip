@@ -1727,7 +1727,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
                                           int* item_next) {
     const long long p = sg.prof_begin + prof_local;
     BlockInfo info = stage_profile<TIER, THREADS>(
-        a.den + p * a.prof_stride, a.bmag + p * a.prof_stride, a.bpsi + p * a.prof_stride,
+        a.den + p * a.prof_stride, a.bmag + p * a.field_stride, a.bpsi + p * a.field_stride,
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
     PRHF_MARK(1);
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);

@@ -53,8 +53,15 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
         raise ValueError("freq and vh_obs must be 1-D arrays of one length")
     d2 = np.atleast_2d(_as_rows("den", den))
     n_prof, n_alt = d2.shape
-    b2, p2 = (np.ascontiguousarray(np.broadcast_to(np.atleast_2d(_as_rows(n, x)), d2.shape))
-              for n, x in (("bmag", bmag), ("bpsi", bpsi)))
+    b2, p2 = (_as_rows(n, x) for n, x in (("bmag", bmag), ("bpsi", bpsi)))
+    # a fit's candidates share the field (library.py:589-591): one row each, said so to the library - no (P, N_alt)
+    # copies on the host, a third of the bytes to upload
+    shared = b2.ndim == 1 and p2.ndim == 1
+    if shared:
+        if b2.shape != (n_alt,) or p2.shape != (n_alt,):
+            raise ValueError("bmag and bpsi must have one value per density level")
+    else:
+        b2, p2 = (np.ascontiguousarray(np.broadcast_to(np.atleast_2d(x), d2.shape)) for x in (b2, p2))
     a = _as_rows("alt", alt)
     if a.shape != (n_alt,):
         raise ValueError("alt must be 1-D with one value per density level")
@@ -68,7 +75,8 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
     _native.raise_for(ctx.vfo_residual(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data,
                                        a.ctypes.data, n_prof, n_alt, n_alt, 0, mult.ctypes.data, int(n_points), code,
                                        obs.ctypes.data, vh.ctypes.data if return_vh else None,
-                                       residual.ctypes.data, cost.ctypes.data, 0))
+                                       residual.ctypes.data, cost.ctypes.data,
+                                       _native.FLAG_SHARED_FIELD if shared else 0))
     out = (residual, cost) if return_cost else (residual,)
     if return_vh:
         out = out + (vh,)

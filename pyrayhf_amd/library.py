@@ -200,8 +200,11 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
         raise ValueError("freq must be a scalar or 1-D")
     d, b, p, a = (_as_rows(n, x) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi), ("alt", alt)))
     single = d.ndim == 1
-    d2, b2, p2 = (np.atleast_2d(x) for x in (d, b, p))
-    if not (d2.shape == b2.shape == p2.shape):
+    # batch extension: one bmag / bpsi row may serve every density row (an ensemble or a fit at one site)
+    shared = d.ndim == 2 and b.ndim == 1 and p.ndim == 1 and b.shape == p.shape == d.shape[1:]
+    d2 = np.atleast_2d(d)
+    b2, p2 = (b, p) if shared else (np.atleast_2d(b), np.atleast_2d(p))
+    if not shared and not (d2.shape == b2.shape == p2.shape):
         logger.error("Error: freq, den, bmag, bpsi, alt should have same size")   # reference library.py:487-488
         raise ValueError("den, bmag and bpsi must have the same shape")
     n_prof, n_alt = d2.shape
@@ -215,7 +218,7 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                        n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
-                       out.ctypes.data, 0)
+                       out.ctypes.data, _native.FLAG_SHARED_FIELD if shared else 0)
     _native.raise_for(rc)
     return out[0] if single else out
 
@@ -296,6 +299,7 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     'X'; for 'O' the reference's order where 1 - X <= 1e-4 - where it decides the answer - and the
     reduced algebra elsewhere, which reproduces the reference to 1e-10),
     and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
+    With 2-D ``den``, 1-D ``bmag`` and ``bpsi`` are one field row shared by every profile (NumPy inputs).
 
     Raises ``ValueError("mode must be 'O' or 'X'")``, ``ValueError("Density must be
     non-negative")`` (reference library.py:395-396, :93-94), ``IndexError`` when the density

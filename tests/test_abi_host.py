@@ -131,7 +131,8 @@ def test_header_constants_match_the_binding():
     expect = {"PRHF_OK": _native.OK, "PRHF_EINVAL": _native.EINVAL, "PRHF_ENEGDEN": _native.ENEGDEN,
               "PRHF_EPEAK0": _native.EPEAK0, "PRHF_EHIP": _native.EHIP, "PRHF_ENOMEM": _native.ENOMEM,
               "PRHF_FLAG_DEVICE_PTRS": _native.FLAG_DEVICE_PTRS, "PRHF_FLAG_ASYNC": _native.FLAG_ASYNC,
-              "PRHF_FLAG_GRID_STABLE": _native.FLAG_GRID_STABLE, "PRHF_MODE_O": _native.MODE_O,
+              "PRHF_FLAG_GRID_STABLE": _native.FLAG_GRID_STABLE, "PRHF_FLAG_SHARED_FIELD": _native.FLAG_SHARED_FIELD,
+              "PRHF_MODE_O": _native.MODE_O,
               "PRHF_MODE_X": _native.MODE_X, "PRHF_MATH_FAITHFUL": _native.MATH_FAITHFUL,
               "PRHF_MATH_FAST": _native.MATH_FAST, "PRHF_MATH_AUTO": _native.MATH_AUTO,
               "PRHF_ABI_VERSION": _native.ABI_VERSION}

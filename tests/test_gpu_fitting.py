@@ -111,3 +111,26 @@ def test_peak_density_from_trace_formulae():
     fc = 4e-5 * 2.799249247e10
     want = library.freq2den(np.sqrt(9.0e6 ** 2 - 9.0e6 * fc)) * 1.0001                       # library.py:774-778
     assert fitting.peak_density_from_trace(9.0, "X", alt=alt, bmag=bmag, hmf2=300.0) == want
+
+
+def test_shared_field_rows_equal_their_broadcast():
+    """PRHF_FLAG_SHARED_FIELD: one bmag / bpsi row for every candidate (what a fit has) gives, bit for bit, what the
+    (P, N_alt) copies of that row give - through the residual entry point and through the operator."""
+    import time
+    from pyrayhf_amd import fitting, library, synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(3000, 31)
+    freq = np.arange(1.0, 12.0, 0.1)
+    obs = library.vertical_forward_operator(freq, den[7], bmag[0], bpsi[0], alt, "O", 200)
+    keep = np.isfinite(obs)
+    t0 = time.perf_counter()
+    r1, c1, v1 = fitting.residual_VH_batch(freq[keep], obs[keep], den, bmag[0], bpsi[0], alt, "O", 200, return_vh=True)
+    t1 = time.perf_counter()
+    wide_b, wide_p = np.tile(bmag[0], (3000, 1)), np.tile(bpsi[0], (3000, 1))
+    r2, c2, v2 = fitting.residual_VH_batch(freq[keep], obs[keep], den, wide_b, wide_p, alt, "O", 200, return_vh=True)
+    t2 = time.perf_counter()
+    assert np.array_equal(r1, r2, equal_nan=True) and np.array_equal(c1, c2, equal_nan=True) and np.array_equal(v1, v2, equal_nan=True)
+    assert int(np.nanargmin(c1)) == 7 and c1[7] < 1e-12          # (a lone profile takes another launch geometry: ~1e-12)
+    print(f"3000 candidates x {keep.sum()} freqs from host arrays: shared field rows {1e3 * (t1 - t0):.2f} ms, broadcast copies {1e3 * (t2 - t1):.2f} ms")
+    a = library.vertical_forward_operator(freq, den[:64], bmag[0], bpsi[0], alt, "X", 2000)
+    b = library.vertical_forward_operator(freq, den[:64], wide_b[:64], wide_p[:64], alt, "X", 2000)
+    assert a.shape == (64, freq.size) and np.array_equal(a, b, equal_nan=True)
