@@ -240,8 +240,11 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
     f = prep(freq, "freq").reshape(-1)
     d, b, p, a = (prep(x, n) for x, n in ((den, "den"), (bmag, "bmag"), (bpsi, "bpsi"), (alt, "alt")))
     single = d.dim() == 1
-    d2, b2, p2 = (x.reshape(1, -1) if x.dim() == 1 else x for x in (d, b, p))
-    if not (d2.shape == b2.shape == p2.shape) or d2.dim() != 2:
+    # (2-D den with 1-D bmag and bpsi: one field row shared by every profile)
+    shared = d.dim() == 2 and b.dim() == 1 and p.dim() == 1 and b.shape == p.shape == d.shape[1:]
+    d2 = d.reshape(1, -1) if single else d
+    b2, p2 = (b, p) if shared else tuple(x.reshape(1, -1) if x.dim() == 1 else x for x in (b, p))
+    if d2.dim() != 2 or (not shared and not (d2.shape == b2.shape == p2.shape)):
         raise ValueError("den, bmag and bpsi must have the same 1-D or 2-D shape")
     n_prof, n_alt = d2.shape
     if a.shape[-1] != n_alt or (a.dim() == 2 and a.shape[0] != n_prof):
@@ -257,7 +260,8 @@ def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync,
     ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
                        n_prof, n_alt, n_alt, alt_stride, mult.data_ptr(), int(n_points), mode_code,
-                       out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC | grid_flag)
+                       out.data_ptr(), _native.FLAG_DEVICE_PTRS | _native.FLAG_ASYNC | grid_flag |
+                       (_native.FLAG_SHARED_FIELD if shared else 0))
     _native.raise_for(rc)
     if sync:
         _native.raise_for(ctx.sync())
@@ -299,7 +303,7 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     'X'; for 'O' the reference's order where 1 - X <= 1e-4 - where it decides the answer - and the
     reduced algebra elsewhere, which reproduces the reference to 1e-10),
     and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
-    With 2-D ``den``, 1-D ``bmag`` and ``bpsi`` are one field row shared by every profile (NumPy inputs).
+    With 2-D ``den``, 1-D ``bmag`` and ``bpsi`` are one field row shared by every profile.
 
     Raises ``ValueError("mode must be 'O' or 'X'")``, ``ValueError("Density must be
     non-negative")`` (reference library.py:395-396, :93-94), ``IndexError`` when the density

@@ -134,3 +134,8 @@ def test_shared_field_rows_equal_their_broadcast():
     a = library.vertical_forward_operator(freq, den[:64], bmag[0], bpsi[0], alt, "X", 2000)
     b = library.vertical_forward_operator(freq, den[:64], wide_b[:64], wide_p[:64], alt, "X", 2000)
     assert a.shape == (64, freq.size) and np.array_equal(a, b, equal_nan=True)
+    import torch
+    dev = torch.device("cuda:0")
+    t = [torch.as_tensor(x, device=dev) for x in (freq, den[:64], bmag[0], bpsi[0], alt)]
+    c = library.vertical_forward_operator(*t, "X", 2000)
+    assert np.array_equal(c.cpu().numpy(), a, equal_nan=True)
