@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PRHF_ABI_VERSION 2   /* 2: + prhf_snell_fan_f64, prhf_recent_kernel_ms (round 2) */
+#define PRHF_ABI_VERSION 2   /* 2: + prhf_snell_fan_f64, prhf_recent_kernel_ms, PRHF_FLAG_SHARED_FIELD (round 2) */
 
 /* return codes */
 #define PRHF_OK        0
