@@ -51,6 +51,8 @@ double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
 int kSplitMinPoints = 1024;                // PRHF_SPLIT_MIN_POINTS
 int kSplitFewProfiles = 1;                 // PRHF_SPLIT_FEW_PROFILES=0: one workgroup per profile whatever their number
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
+int kShortKernel = 1;                      // PRHF_SHORT_KERNEL=0: short O-mode grids stay in the general kernel (A/B runs)
+int kShortQueueFixed = 0;                  // PRHF_SHORT_QUEUE=n: the short-grid kernel's queue holds exactly n entries (tests)
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
@@ -118,9 +120,11 @@ struct prhf_ctx {
     DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
     DevBuf ftab;      // per-frequency scalars of a long launch
     DevBuf levels;    // level table of a grouped tracer launch
+    DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
-    unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1] block queue of persistent launches
+    unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1..3] block queues of persistent launches (general,
+                                    // short-grid, its follow-up)
     unsigned* h_status = nullptr;   // pinned
     double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece
     unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
@@ -237,11 +241,20 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 
     ENTER_DEVICE(c->device);
 
+    const int n_user_segs = n_segs;
     prhf::KArgs a;
     std::memset(&a, 0, sizeof a);
     a.n_freq = n_freq;
     a.n_alt = n_alt;
     a.n_segs = n_segs;
+    // Slices of short O-mode grids leave for a launch of their own (vfo_short_kernel): `a` keeps the others
+    prhf::SegDev short_seg[PRHF_MAX_SEGMENTS];
+    int n_short = 0;
+    // LDS budget of a short-grid workgroup: two per CU where its nodes allow that, else one (a few hundred bytes of
+    // static LDS - tickets, counters - come on top)
+    const size_t lds_half = 80 * 1024 - 512, lds_full = 160 * 1024 - 512;
+    const size_t short_budget = prhf::short_queue_entries(n_alt, n_freq, lds_half) ? lds_half : lds_full;
+    const int short_queue = prhf::short_queue_entries(n_alt, n_freq, short_budget);
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
     int launch_tier = 0;
     bool want_pairs = false;
@@ -287,6 +300,35 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.thread_scan = ((double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
         plan_slice(s, n_freq, wg_slots);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
+    }
+    // (a.seg[i] was filled for every slice; now the short-grid slices move out and the others close ranks)
+    {
+        int kept = 0;
+        for (int i = 0; i < n_segs; ++i) {
+            const prhf::SegDev& s = a.seg[i];
+            // the short-grid kernel reads the per-frequency table (launches of >= 4096 pairs), settles the
+            // reflection heights per thread (n_freq <= n_alt) and lists at most PRHF_MAX_CAND frequencies
+            const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && s.lean && s.chunks == 1 &&
+                                  s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
+                                  n_freq <= n_alt && n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 &&
+                                  !kNoCandidates && short_queue > 0;
+            if (is_short) {
+                prhf::SegDev& t = short_seg[n_short++];
+                t = s;
+                t.blocks_per_prof = 1;
+                t.tail_prof = t.prof_end - t.prof_begin;
+                t.tail_bpp = 1;
+                t.group = 1;                       // (the follow-up launch of the general kernel: one pair per item)
+                t.prio = 0;
+            } else {
+                if (kept != i) a.seg[kept] = a.seg[i];
+                ++kept;
+            }
+        }
+        n_segs = kept;
+        a.n_segs = kept;
+        launch_tier = 0;
+        for (int i = 0; i < kept; ++i) launch_tier = (i == 0 || launch_tier == a.seg[i].tier) ? a.seg[i].tier : 2;
     }
     // Workgroups are dispatched roughly in index order: give the slices with the most work per workgroup
     // the lowest indices so that a mixed launch does not end on its longest workgroups.
@@ -386,7 +428,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         a.out = d_out;
         // rows that no segment covers must come back as NaN, not as whatever the arena held (all-ones bytes = NaN)
         long long covered = 0;
-        for (int i = 0; i < n_segs; ++i) covered += segs[i].prof_end - segs[i].prof_begin;
+        for (int i = 0; i < n_user_segs; ++i) covered += segs[i].prof_end - segs[i].prof_begin;
         if (covered < out_rows && out_elems) HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_elems * 8, c->stream));
         a.prof_stride = n_alt;
         a.field_stride = shared_field ? 0 : n_alt;
@@ -425,7 +467,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         // per-frequency scalars: long launches read them from a table instead of dividing once per pair (a short
         // launch - one profile - is latency bound: it does without the extra kernel)
         if (n_prof * n_freq >= 4096) {
-            if ((rc = ensure(c, c->ftab, (size_t)n_freq * 64)) != PRHF_OK) return rc;
+            if ((rc = ensure(c, c->ftab, ((size_t)n_freq + 1) * 64)) != PRHF_OK) return rc;
             HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), c->stream));
             a.ftab = static_cast<const double*>(c->ftab.p);
         }
@@ -442,11 +484,48 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 #endif
     a.n_blocks = blocks;
     a.no_candidates = kNoCandidates;
+    HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 3 * sizeof(unsigned), c->stream));     // the launches' block queues
+    if (n_short > 0) {
+        // Short O-mode grids: vfo_short_kernel, then the general kernel over the profiles it left on its list
+        // (non-uniform altitude grid, fast-turning or vanishing field, negative density, peak at level 0 or 1)
+        prhf::KArgs as = a;
+        as.n_segs = n_short;
+        long long short_blocks = 0;
+        for (int i = 0; i < n_short; ++i) {
+            short_seg[i].block_begin = short_blocks;
+            short_blocks += short_seg[i].prof_end - short_seg[i].prof_begin;
+            as.seg[i] = short_seg[i];
+        }
+        if (short_blocks > 0x7fffffffLL) return fail(PRHF_EINVAL, "launch too large");
+        as.n_blocks = short_blocks;
+        as.short_queue = kShortQueueFixed > 0 ? -std::min(kShortQueueFixed, short_queue) : short_queue;
+        as.partial = nullptr;
+        as.altmin = nullptr;
+        as.trace = nullptr;
+        if (short_blocks > 0) {
+            if ((rc = ensure(c, c->leftover, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rc;
+            as.leftover = static_cast<unsigned*>(c->leftover.p);
+            HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), c->stream));
+            const long long short_slots = (long long)c->cu_count * (short_budget == lds_half ? 2 : 1);
+            long long grid_short = short_blocks;
+            as.queue = nullptr;
+            if (short_blocks > short_slots) {
+                as.queue = c->d_status + 2;
+                grid_short = short_slots;
+            }
+            HIP_TRY(prhf::launch_vfo_short(as, grid_short, prhf::short_lds_fixed(n_alt, n_freq) + 8 * (size_t)short_queue,
+                                           c->stream));
+            prhf::KArgs af = as;
+            af.block_list = as.leftover;
+            af.leftover = nullptr;
+            af.queue = c->d_status + 3;
+            HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), 0, prhf::lds_bytes_for(n_alt), c->stream));
+        }
+    }
     long long grid_blocks = blocks;
     if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
         a.queue = c->d_status + 1;
         grid_blocks = wg_slots;
-        HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), c->stream));
     }
     HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
 #ifdef PRHF_TRACE
@@ -518,6 +597,8 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* sf = std::getenv("PRHF_SPLIT_FEW_PROFILES")) kSplitFewProfiles = std::atoi(sf);
     if (const char* sm = std::getenv("PRHF_SPLIT_MIN_POINTS")) kSplitMinPoints = std::atoi(sm);
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
+    if (const char* sk = std::getenv("PRHF_SHORT_KERNEL")) kShortKernel = std::atoi(sk);
+    if (const char* sq = std::getenv("PRHF_SHORT_QUEUE")) kShortQueueFixed = std::atoi(sq);
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -530,10 +611,10 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 2 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 4 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
             hipSuccess ||
-        (e = hipMemset(c->d_status, 0, 2 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_status, 0, 4 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_words), 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 2 * sizeof(unsigned long long),
@@ -559,6 +640,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->pairs.p) (void)hipFree(c->pairs.p);
     if (c->ftab.p) (void)hipFree(c->ftab.p);
     if (c->levels.p) (void)hipFree(c->levels.p);
+    if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_pack) (void)hipHostFree(c->h_pack);

@@ -21,6 +21,10 @@
 #define PRHF_MAX_SEGMENTS 8
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 96          // one staged bottomside level
+#define PRHF_SNODE_BYTES 80         // ... of the short-grid kernel (20 dwords: conflict-free under ds_read_b128)
+#define PRHF_SHORT_MIN_POINTS 65    // grids of 65 .. 1024 points in the default O-mode arithmetic: vfo_short_kernel
+#define PRHF_SHORT_MAX_POINTS 1024  // (16 wave-iterations: one violation mask each, per wave)
+#define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
 #define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
 #ifndef PRHF_TOP_MIN_POINTS
 #define PRHF_TOP_MIN_POINTS 1024    // grids from this many points on give their top segment a loop of its own
@@ -81,6 +85,10 @@ struct KArgs {
     long long field_stride;          // row stride of bmag and bpsi: prof_stride, or 0 when one row serves every profile
     int n_segs;
     int no_candidates;               // PRHF_NO_CANDIDATES=1 (A/B runs): every frequency is a work item, none is pre-filtered
+    // Short-grid launches (vfo_short_kernel) and their follow-up:
+    unsigned* leftover;              // [0] count, [1..] block indices of the profiles the short-grid kernel does not take
+    const unsigned* block_list;      // general kernel: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
+    int short_queue;                 // entries of the short-grid kernel's LDS queue
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 
@@ -91,16 +99,37 @@ inline size_t lds_bytes_for(long long n_alt) {
            PRHF_RED_DOUBLES * 8;
 }
 
+// LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
+// nodes, then `queue` entries of 8 bytes (a profile with K < n_alt levels adds its unused nodes to the queue).
+inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq) {
+    const size_t b = (size_t)n_alt * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_BLOCK_THREADS / 64) * 16 * 12 +
+                     PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 4 + (size_t)n_freq * 2;
+    return (b + 15) & ~(size_t)15;
+}
+inline size_t short_lds_fixed(long long n_alt, long long n_freq) {
+    return short_lds_lists(n_alt, n_freq) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
+}
+// queue entries that fit `budget` bytes beside a full node table (0: the kernel cannot run)
+inline int short_queue_entries(long long n_alt, long long n_freq, size_t budget) {
+    const size_t fixed = short_lds_fixed(n_alt, n_freq);
+    if (fixed + 8 * 64 > budget) return 0;
+    const size_t q = (budget - fixed) / 8;
+    return (int)(q > PRHF_SHORT_MAX_QUEUE ? PRHF_SHORT_MAX_QUEUE : q);
+}
+
 hipError_t configure_kernels(size_t max_lds_bytes);
 hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
 // pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]; `pairs` holds n + PRHF_PAIR_PAD entries
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
-// tab[8 f ..] = f_hz, f2, cp^2/f2, (g_p/f)^2, 1/f2, 1/f_hz, 0, 0
+// tab[8 f ..] = f_hz, f2, cp^2/f2, (g_p/f)^2, 1/f2, 1/f_hz, 0, 0; row n_freq: min |freq_mhz| (tab holds n_freq + 1 rows)
 hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 // a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull
 // block indices from the queue, else grid_blocks must equal a.n_blocks
 hipError_t launch_vfo(const KArgs& a, long long grid_blocks, int tier, size_t lds_bytes, hipStream_t stream);
+// the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
+// lds_bytes = short_lds_fixed + 8 a.short_queue
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
                          unsigned long long* absmax_scratch, unsigned long long* absmax_host,

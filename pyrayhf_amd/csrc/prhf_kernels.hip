@@ -1793,7 +1793,12 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
     __shared__ long long next_bid;
     __shared__ int item_next;
     __shared__ int cand_count[PRHF_BLOCK_THREADS / 64 + 1];
-    long long bid = blockIdx.x;
+    // Follow-up of a short-grid launch: the blocks to evaluate are listed (block_list[1 .. block_list[0]])
+    const unsigned* list = a.block_list;
+    const long long n_blocks = list ? (long long)list[0] : a.n_blocks;
+    long long ticket = blockIdx.x;
+    if (ticket >= n_blocks) return;
+    long long bid = list ? (long long)list[1 + ticket] : ticket;
     for (;;) {
         if (threadIdx.x == 0) item_next = 0;   // ordered before its first use by the barriers of stage_profile
 #ifdef PRHF_TRACE
@@ -1828,7 +1833,7 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
             // one slice: the blocks of the last three resident rounds rank below everything pulled before them, round
             // by round, so that the launch ends on its newest (and, in the last round, quartered) blocks and not on
             // an old one that its neighbour kept waiting
-            const long long left = a.n_blocks - bid, round = gridDim.x;
+            const long long left = n_blocks - ticket, round = gridDim.x;
             prio = left > 3 * round ? 3 : (left > 2 * round ? 2 : (left > round ? 1 : 0));
         }
         if (a.n_segs > 1 || a.queue != nullptr) {
@@ -1859,8 +1864,9 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         __syncthreads();                       // every wave is done with the staged profile (and with next_bid)
         if (threadIdx.x == 0) next_bid = (long long)gridDim.x + atomicAdd(a.queue, 1u);
         __syncthreads();
-        bid = uniform((int)next_bid);
-        if (bid >= a.n_blocks) break;
+        ticket = uniform((int)next_bid);
+        if (ticket >= n_blocks) break;
+        bid = list ? (long long)list[1 + ticket] : ticket;
     }
 }
 
@@ -1902,10 +1908,29 @@ __global__ void freq_table_kernel(const double* __restrict__ freq_mhz, long long
     row[4] = 1.0 / f2; row[5] = 1.0 / f_hz; row[6] = 0.0; row[7] = 0.0;
 }
 
+// Row n_freq of the table: min |freq_mhz| over the launch (the isotropic test of library.py:201 needs the lowest
+// frequency; the short-grid kernel reads it here instead of scanning the frequencies once per profile).
+__global__ void freq_min_kernel(const double* __restrict__ freq_mhz, long long n_freq, double* __restrict__ tab) {
+    __shared__ double part[4];
+    double fm = __builtin_inf();
+    for (long long i = threadIdx.x; i < n_freq; i += blockDim.x) fm = fmin(fm, fabs(freq_mhz[i]));
+    fm = wave_min(fm);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = fm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* row = tab + 8 * n_freq;
+        row[0] = fmin(fmin(part[0], part[1]), fmin(part[2], part[3]));
+        for (int k = 1; k < 8; ++k) row[k] = 0.0;
+    }
+}
+
 hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream) {
     if (n_freq <= 0) return hipSuccess;
     hipLaunchKernelGGL(freq_table_kernel, dim3((unsigned)((n_freq + 255) / 256)), dim3(256), 0, stream, freq_mhz, n_freq,
                        tab);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(freq_min_kernel, dim3(1), dim3(256), 0, stream, freq_mhz, n_freq, tab);
     return hipGetLastError();
 }
 
@@ -2253,6 +2278,15 @@ hipError_t launch_residual(const double* vh_model, const double* vh_obs, long lo
     return hipGetLastError();
 }
 
+#include "prhf_short.inc"
+
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
+    constexpr int THREADS = PRHF_BLOCK_THREADS;
+    if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((vfo_short_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
 #include "prhf_snell.inc"
 
 // Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
@@ -2270,6 +2304,7 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
     const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
+                             reinterpret_cast<const void*>(&vfo_short_kernel<THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);

@@ -97,8 +97,10 @@ def test_brute_force_recovers_the_generating_profile():
     obs_noisy = obs.copy()
     obs_noisy[3] = np.nan                                # a missing sounding is filtered out (library.py:742)
     best, cost, vh_best, f_used = fitting.brute_force_fit(freq[::-1], obs_noisy[::-1], den, bmag, bpsi, alt, "O", 200)
-    assert best == truth and cost[truth] < 1e-12 and f_used.size == freq.size - 1
-    np.testing.assert_allclose(vh_best, np.delete(obs, 3), rtol=1e-12)      # the modeled trace itself, NaNs kept
+    # (the lone profile behind `obs` runs in the general kernel, the 231 candidates in the short-grid kernel: the two
+    #  choose between the reduced algebra and the reference's order per wave-iteration and per point - ~1e-10 apart)
+    assert best == truth and cost[truth] < 1e-10 and f_used.size == freq.size - 1
+    np.testing.assert_allclose(vh_best, np.delete(obs, 3), rtol=1e-9)       # the modeled trace itself, NaNs kept
     assert np.all(np.diff(f_used) > 0)
     assert cost.shape == (len(grid),) and np.sum(cost < 1.0) == 1
 
@@ -129,7 +131,7 @@ def test_shared_field_rows_equal_their_broadcast():
     r2, c2, v2 = fitting.residual_VH_batch(freq[keep], obs[keep], den, wide_b, wide_p, alt, "O", 200, return_vh=True)
     t2 = time.perf_counter()
     assert np.array_equal(r1, r2, equal_nan=True) and np.array_equal(c1, c2, equal_nan=True) and np.array_equal(v1, v2, equal_nan=True)
-    assert int(np.nanargmin(c1)) == 7 and c1[7] < 1e-12          # (a lone profile takes another launch geometry: ~1e-12)
+    assert int(np.nanargmin(c1)) == 7 and c1[7] < 1e-10          # (a lone profile takes another kernel: ~1e-10 apart)
     print(f"3000 candidates x {keep.sum()} freqs from host arrays: shared field rows {1e3 * (t1 - t0):.2f} ms, broadcast copies {1e3 * (t2 - t1):.2f} ms")
     a = library.vertical_forward_operator(freq, den[:64], bmag[0], bpsi[0], alt, "X", 2000)
     b = library.vertical_forward_operator(freq, den[:64], wide_b[:64], wide_p[:64], alt, "X", 2000)
