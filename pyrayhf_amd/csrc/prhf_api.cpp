@@ -52,6 +52,7 @@ int kSplitMinPoints = 1024;                // PRHF_SPLIT_MIN_POINTS
 int kSplitFewProfiles = 1;                 // PRHF_SPLIT_FEW_PROFILES=0: one workgroup per profile whatever their number
 int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
 int kShortKernel = 1;                      // PRHF_SHORT_KERNEL=0: short O-mode grids stay in the general kernel (A/B runs)
+int kShortConcurrent = 1;                  // PRHF_SHORT_CONCURRENT=0: short-grid and general launch of a mixed list one after the other
 int kShortQueueFixed = 0;                  // PRHF_SHORT_QUEUE=n: the short-grid kernel's queue holds exactly n entries (tests)
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
@@ -101,6 +102,8 @@ hipError_t create_events(hipEvent_t* ev, int n) {
 struct prhf_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // mixed lists: the short-grid launch runs beside the general one (fork / join by events)
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     hipStream_t stream = nullptr;
     // start / stop events of the most recent launches, a ring: a caller that enqueues many launches without
     // synchronising can still read every one's device time afterwards (prhf_recent_kernel_ms)
@@ -476,7 +479,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // diagnostics build (tools/wave_trace.py): per-wave wall-clock stamps of this launch, dumped to $PRHF_TRACE_FILE
     static DevBuf trace_buf;
     const size_t trace_words = (size_t)blocks * kWavesPerBlock * 6;   // start, end, staged, and three staging marks
-    if (std::getenv("PRHF_TRACE_FILE")) {
+    if (std::getenv("PRHF_TRACE_FILE") && blocks > 0) {
         if ((rc = ensure(c, trace_buf, trace_words * 8)) != PRHF_OK) return rc;
         HIP_TRY(hipMemsetAsync(trace_buf.p, 0, trace_words * 8, c->stream));
         a.trace = static_cast<unsigned long long*>(trace_buf.p);
@@ -485,6 +488,27 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     a.n_blocks = blocks;
     a.no_candidates = kNoCandidates;
     HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 3 * sizeof(unsigned), c->stream));     // the launches' block queues
+    // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
+    // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
+    // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
+    // on a few long blocks.  (One after the other on one stream the config-5 shard took 8.04 ms, general kernel alone
+    // 7.94 ms.)  Fork and join by events; a launch of one kind stays on the caller's stream.
+    auto launch_general = [&]() -> int {
+        long long grid_blocks = blocks;
+        if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
+            a.queue = c->d_status + 1;
+            grid_blocks = wg_slots;
+        }
+        HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+        return PRHF_OK;
+    };
+    const bool forked = n_short > 0 && blocks > 0 && kShortConcurrent;
+    hipStream_t short_stream = forked ? c->aux_stream : c->stream;
+    if (forked) {
+        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));        // tables, queues and inputs are in place
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
+        if ((rc = launch_general()) != PRHF_OK) return rc;
+    }
     if (n_short > 0) {
         // Short O-mode grids: vfo_short_kernel, then the general kernel over the profiles it left on its list
         // (non-uniform altitude grid, fast-turning or vanishing field, negative density, peak at level 0 or 1)
@@ -502,10 +526,19 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         as.partial = nullptr;
         as.altmin = nullptr;
         as.trace = nullptr;
+#ifdef PRHF_TRACE
+        static DevBuf trace_short;
+        const size_t short_trace_words = (size_t)short_blocks * kWavesPerBlock * 8;
+        if (std::getenv("PRHF_TRACE_FILE") && short_blocks > 0) {
+            if ((rc = ensure(c, trace_short, short_trace_words * 8)) != PRHF_OK) return rc;
+            HIP_TRY(hipMemsetAsync(trace_short.p, 0, short_trace_words * 8, short_stream));
+            as.trace = static_cast<unsigned long long*>(trace_short.p);
+        }
+#endif
         if (short_blocks > 0) {
             if ((rc = ensure(c, c->leftover, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rc;
             as.leftover = static_cast<unsigned*>(c->leftover.p);
-            HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), c->stream));
+            HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
             const long long short_slots = (long long)c->cu_count * (short_budget == lds_half ? 2 : 1);
             long long grid_short = short_blocks;
             as.queue = nullptr;
@@ -514,20 +547,32 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 grid_short = short_slots;
             }
             HIP_TRY(prhf::launch_vfo_short(as, grid_short, prhf::short_lds_fixed(n_alt, n_freq) + 8 * (size_t)short_queue,
-                                           c->stream));
+                                           short_stream));
+#ifdef PRHF_TRACE
+            if (as.trace) {                        // eight wall-clock marks per wave and block (tools/wave_trace_short.py)
+                std::vector<unsigned long long> host(short_trace_words);
+                HIP_TRY(hipMemcpyAsync(host.data(), as.trace, short_trace_words * 8, hipMemcpyDeviceToHost, short_stream));
+                HIP_TRY(hipStreamSynchronize(short_stream));
+                if (FILE* fp = std::fopen(std::getenv("PRHF_TRACE_FILE"), "wb")) {
+                    std::fwrite(host.data(), 8, short_trace_words, fp);
+                    std::fclose(fp);
+                }
+            }
+#endif
             prhf::KArgs af = as;
+            af.trace = nullptr;
             af.block_list = as.leftover;
             af.leftover = nullptr;
             af.queue = c->d_status + 3;
-            HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), 0, prhf::lds_bytes_for(n_alt), c->stream));
+            HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), 0, prhf::lds_bytes_for(n_alt), short_stream));
         }
     }
-    long long grid_blocks = blocks;
-    if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
-        a.queue = c->d_status + 1;
-        grid_blocks = wg_slots;
+    if (forked) {
+        HIP_TRY(hipEventRecord(c->join_ev, c->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
+    } else {
+        if ((rc = launch_general()) != PRHF_OK) return rc;
     }
-    HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
 #ifdef PRHF_TRACE
     if (a.trace) {
         std::vector<unsigned long long> host(trace_words);
@@ -599,6 +644,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
     if (const char* sk = std::getenv("PRHF_SHORT_KERNEL")) kShortKernel = std::atoi(sk);
     if (const char* sq = std::getenv("PRHF_SHORT_QUEUE")) kShortQueueFixed = std::atoi(sq);
+    if (const char* sc = std::getenv("PRHF_SHORT_CONCURRENT")) kShortConcurrent = std::atoi(sc);
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -609,6 +655,9 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     c->device = device;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 4 * sizeof(unsigned))) != hipSuccess ||
@@ -650,6 +699,9 @@ int prhf_ctx_destroy(prhf_ctx* c) {
         if (c->ring0[i]) (void)hipEventDestroy(c->ring0[i]);
         if (c->ring1[i]) (void)hipEventDestroy(c->ring1[i]);
     }
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PRHF_OK;

@@ -42,8 +42,9 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     child(sys.argv[2], int(sys.argv[3]))
     sys.exit(0)
 n_prof = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-for tag, knob, qfix in (("general", "0", "0"), ("short", "1", "0"), ("tinyq", "1", "40")):
-    env = dict(os.environ, PRHF_SHORT_KERNEL=knob, PRHF_SHORT_QUEUE=qfix)
+for tag, knob, qfix, conc in (("general", "0", "0", "1"), ("short", "1", "0", "1"), ("tinyq", "1", "40", "1"),
+                              ("sequential", "1", "0", "0")):
+    env = dict(os.environ, PRHF_SHORT_KERNEL=knob, PRHF_SHORT_QUEUE=qfix, PRHF_SHORT_CONCURRENT=conc)
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", tag, str(n_prof)], env=env, check=True)
 for key in ("n200", "n500", "n1000", "c5"):
     b = np.load(os.path.join(ROOT, "gpurun_out", f"ab_short_short_{key}.npy"))
