@@ -171,14 +171,81 @@ def config5_segments(world, profiles_per_gpu=None):
 # ------------------------------------------------------------------------------------------------
 # launcher
 # ------------------------------------------------------------------------------------------------
+def extra_legs(torch, dev, ctx, library, synth, pdist, math):
+    """config3, config5_shard, config4_full: each {ms, integrals_per_s, roofline, ...} (see main)."""
+    prof_json = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    traffic_rec = json.load(open(prof_json)) if os.path.exists(prof_json) else {}
+    legs = {}
+
+    def leg(name, what, freq, alt, den, bmag, bpsi, segments, steps, warmup, key):
+        """segments: [(p0, p1, mode, n_points)] over the rows of den; one launch per step.  Host arrays or tensors
+        on `dev`; the nominal flop count (algorithmic_flops) is taken on the device."""
+        tt = [torch.as_tensor(x, device=dev) for x in (freq, den, bmag, bpsi, alt)]
+        single = len(segments) == 1
+        mode, n_points = segments[0][2], segments[0][3]
+        outs = None
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            if single:
+                outs = library.vertical_forward_operator(*tt, mode, n_points, math=math, sync=False, out=outs)
+            else:
+                outs = library.vertical_forward_operator_mixed(*tt, segments, math=math, sync=False)
+        torch.cuda.synchronize(dev)
+        wall_ms = 1e3 * (time.perf_counter() - t0) / steps
+        k_ms = float(np.mean(ctx.recent_kernel_ms(steps)))
+        n_prof, n_freq, n_alt = int(tt[1].shape[0]), int(tt[0].numel()), int(tt[4].numel())
+        n_points_row = torch.as_tensor(np.concatenate([np.full(p1 - p0, n) for p0, p1, _, n in segments]),
+                                       dtype=torch.float64, device=dev)
+        integrated = torch.isfinite(outs) & (outs - tt[4].min() > 1e-9)          # integrated_pairs()
+        aflops = float((FLOPS_PER_POINT * n_points_row * integrated.sum(dim=1)).sum()
+                       + (FLOPS_PER_LEVEL * torch.argmax(tt[1], dim=1).double() * n_freq).sum())
+        abytes = algorithmic_bytes(n_prof, n_alt, n_freq, sum(n for _, _, _, n in segments))
+        rec = traffic_rec.get(key, {})
+        pairs = n_prof * n_freq
+        legs[name] = {
+            "workload": what, "steps": steps, "ms": k_ms, "ms_per_step_wall": wall_ms,
+            "integrals_per_s": pairs / (k_ms * 1e-3), "pairs_per_step": pairs,
+            "reflecting_fraction": float(integrated.double().mean()),
+            "roofline": {"bound": "fp64_valu", "achieved": aflops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": aflops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                         "traffic": rec.get("hbm_bytes_per_launch"), "traffic_key": key if rec else None,
+                         "algorithmic_bytes": abytes},
+        }
+        del tt, outs, integrated
+        torch.cuda.empty_cache()
+
+    alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
+    f3 = synth.sounder_frequencies(3)
+    leg("config3", "BASELINE configs[2]: 10000 synthetic Chapman profiles x 174 freqs, O-mode, n_points=200, seed 20260003",
+        f3, alt, den, bmag, bpsi, [(0, 10000, "O", 200)], 20, 3, "O_200_10000x174")
+    rows, segs = pdist.shard_segments(CONFIG5_SEGMENTS, 8, 0)
+    alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=rows)
+    f5 = synth.sounder_frequencies(5)
+    leg("config5_shard", "BASELINE configs[4] per-GPU shard: " + ", ".join(f"{p1 - p0} x {m}/{n}" for p0, p1, m, n in segs) +
+        f" x {f5.size} freqs, ONE work-list launch, seed 20260005", f5, alt, den, bmag, bpsi, segs, 10, 2,
+        f"mixed_0_{rows.size}x{f5.size}")
+    alt, den, bmag, bpsi = synth.chapman_profiles_torch(100000, 20260004, dev)       # (NumPy would take ~10 s on the host)
+    f4 = synth.sounder_frequencies(4)
+    leg("config4_full", "BASELINE configs[3] in full on ONE GPU: 100000 synthetic Chapman profiles x 256 freqs, X-mode, "
+        "n_points=20000, one launch, seed 20260004 (profiles built on the device)", f4, alt, den, bmag, bpsi, [(0, 100000, "X", 20000)], 3, 1,
+        "X_20000_100000x256")
+    return legs
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) and wait.
 
     This parent never touches the GPU (no torch.cuda call, no libprhf): the ranks are fresh child
     processes of `python -m torch.distributed.run`, whose stdout (rank 0's JSON line) passes through."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this image)
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -200,6 +267,11 @@ def main():
     ap.add_argument("--math", default=None, choices=[None, "faithful", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-profile", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the extra driver-timed legs (config3, config5_shard, config4_full) of the default run")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: initialise the process group anyway and push the result rows through the real "
+                         "all_gather_into_tensor (RCCL with one rank) - the N > 1 code path on one GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -232,13 +304,18 @@ def main():
                          "(PRHF_BENCH_BACKEND=gloo rehearses N ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    world_seen = dist.get_world_size() if world > 1 else 1
+    world_seen = dist.get_world_size() if collective else 1
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
     ctx = _native.context(local_rank)
@@ -289,28 +366,36 @@ def main():
          (("freq", freq), ("alt", alt), ("den", den), ("bmag", bmag), ("bpsi", bpsi))}
     out = torch.empty((p_gpu, n_freq), dtype=torch.float64, device=dev)
 
+    gather_events = []                       # (before, after) the gather of every step, on torch's current stream
+
     def step():
         nonlocal out
         if local_segs is not None:
             out = library.vertical_forward_operator_mixed(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"],
                                                           local_segs, math=math, sync=False)
-            if world > 1:
-                pdist.gather_mixed(out, global_segs, max(p1 for _, p1, _, _ in global_segs))
-            return
-        library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], mode, n_points,
-                                          math=math, sync=False, out=out)
-        if world > 1:
-            pdist.gather_rows(out, p_total)
+        else:
+            library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], mode, n_points,
+                                              math=math, sync=False, out=out)
+        if collective:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if local_segs is not None:
+                pdist.gather_mixed(out, global_segs, max(p1 for _, p1, _, _ in global_segs), force=True)
+            else:
+                pdist.gather_rows(out, p_total, force=True)
+            e1.record()
+            gather_events.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
     fence()
+    gather_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()                               # enqueued back to back: no host round trip inside the timed region
@@ -320,10 +405,21 @@ def main():
     # HIP events on the launch stream, recorded by the library around every launch of the timed region
     # (the context remembers the last 64)
     kernel_ms = ctx.recent_kernel_ms(min(args.steps, 64))
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else None
+    kernel_ms_per_rank = None
+    if collective:
+        side = dev if backend == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=side)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank's mean kernel time and gather time, so that a scaling loss can be attributed
+        mine = torch.tensor([float(np.mean(kernel_ms)), gather_ms or 0.0], dtype=torch.float64, device=side)
+        every = torch.empty((world_seen, 2), dtype=torch.float64, device=side)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.cpu().numpy()
+        kernel_ms_per_rank = {"min": float(every[:, 0].min()), "max": float(every[:, 0].max()),
+                              "ranks": [float(v) for v in every[:, 0]]}
+        gather_ms = float(every[:, 1].max())
 
     if rank == 0:
         vh = out.cpu().numpy()
@@ -359,7 +455,9 @@ def main():
                        "mode": mode, "n_alt": int(alt.size), "math": args.math or "default",
                        "parallelism": (f"profile shards x{world}, one process per GPU, all_gather of vh rows over "
                                        f"{'RCCL' if backend == 'nccl' else backend}") if world > 1 else "single GPU"},
-            "world_size_seen": world_seen, "backend": backend if world > 1 else None,
+            "world_size_seen": world_seen, "backend": backend if collective else None,
+            "kernel_ms_per_rank": kernel_ms_per_rank,
+            "gather_ms": gather_ms,          # the slowest rank's mean time in the all-gather of the result rows (null: no collective)
             "reflecting_fraction": float(integrated_pairs(vh, alt).mean()),
             "finite_fraction": float(np.isfinite(vh).mean()),
             "workgroups_per_cu": ctx.occupancy(alt.size, default_tier),
@@ -408,6 +506,16 @@ def main():
             result["host_buffers"] = {"integrals_per_s": p_gpu * n_freq / dt2, "ms_per_call": 1e3 * dt2,
                                       "note": "PCIe-inclusive (pageable host memory in and out); never `value`"}
 
+        if world == 1 and not args.no_legs and args.workload == "config4" and args.profiles is None:
+            # The other BASELINE configurations that fit one GPU, timed by the same process right behind the headline
+            # region (kernel time from the library's HIP events; inputs resident in HBM): BASELINE configs[2], the
+            # per-GPU shard of configs[4] as ONE work-list launch, and configs[3] in full (100 000 x 256) as one launch.
+            del out
+            for k in ("den", "bmag", "bpsi"):
+                t.pop(k)
+            torch.cuda.empty_cache()
+            result.update(extra_legs(torch, dev, ctx, library, synth, pdist, math))
+
         if world == 1 and not args.no_cpu_baseline:
             # bounded samples of the same workload (for config 5: its X/20000 slice, where the CPU time goes)
             if local_segs is not None:
@@ -425,7 +533,7 @@ def main():
             result["cpu_baseline_fused_c"] = cpu_baseline_c(freq, alt, d, b, p, b_mode, b_n, what)
         os.write(json_fd, (json.dumps(result) + "\n").encode())
 
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,12 +31,13 @@
 extern "C" {
 #endif
 
-#define PRHF_ABI_VERSION 2   /* 2: + prhf_snell_fan_f64, prhf_recent_kernel_ms, PRHF_FLAG_SHARED_FIELD (round 2) */
+#define PRHF_ABI_VERSION 3   /* 2: + prhf_snell_fan_f64, prhf_recent_kernel_ms, PRHF_FLAG_SHARED_FIELD (round 2)
+                              * 3: + prhf_ctx_set_option (round 3) */
 
 /* return codes */
 #define PRHF_OK        0
 #define PRHF_EINVAL   -1   /* null pointer, bad shape, n_points < 1, bad mode, bad flag combination, bad segment or index,
-                            * a host-buffer frequency that is not positive and finite */
+                            * a host-buffer multiplier grid that decreases, an unknown option */
 #define PRHF_ENEGDEN  -2   /* a density below the peak is negative (reference library.py:93-94 raises ValueError) */
 #define PRHF_EPEAK0   -3   /* density peak at index 0: empty bottomside (the reference raises IndexError) */
 #define PRHF_EHIP     -4   /* HIP runtime failure; message carries hipGetErrorString */
@@ -96,6 +97,20 @@ int prhf_ctx_set_stream(prhf_ctx* ctx, void* hip_stream, int32_t borrow);
 /* Select the arithmetic tier (PRHF_MATH_*), default PRHF_MATH_AUTO. */
 int prhf_ctx_set_math(prhf_ctx* ctx, int level);
 
+/* Launch-shaping and arithmetic settings of this context, by name (tests and A/B measurements; the defaults are
+ * the measured best and no caller needs to touch them).  The library reads no environment variable: only a
+ * -DPRHF_DIAG build presets these from PRHF_<NAME> at context creation.  PRHF_EINVAL for an unknown name or a
+ * value outside the option's range.
+ *   "well_conditioned"   default O-mode arithmetic: the reference's operation order where 1 - X <= this (1e-5)
+ *   "short_kernel"       0: short O-mode grids (65 .. 1024 points) stay in the general kernel (1)
+ *   "short_concurrent"   0: a mixed list runs its short-grid and general launches one after the other (1)
+ *   "short_queue"        > 0: the short-grid kernel's queue of ill-conditioned points holds exactly this many entries (0)
+ *   "persistent", "tail_bpp", "tail_rounds", "split_few_profiles", "split_min_points", "target_waves"
+ *                        how a launch is cut into workgroups (never the value of a pair)
+ *   "no_candidates", "thread_scan_min", "lean_min_points"
+ *                        which of the equivalent search / loop paths a pair takes */
+int prhf_ctx_set_option(prhf_ctx* ctx, const char* name, double value);
+
 /*
  * Virtual heights of n_prof profiles x n_freq sounder frequencies.
  *
@@ -109,7 +124,10 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *   alt         (n_alt) shared by all profiles when alt_stride_elems == 0, else row p at
  *               alt + p*alt_stride_elems; ascending
  *   multiplier  (n_points) stretched unit grid, smooth_nonuniform_grid(0,1,n_points,10.)
- *               (library.py:296-321, :361-364) computed by the host in float64
+ *               (library.py:296-321, :361-364) computed by the host in float64; values in [0, 1] and
+ *               NON-DECREASING (the main loop's top-segment search relies on it: PRHF_EINVAL for a host
+ *               buffer that decreases; a device-resident grid is the caller's responsibility)
+ *   A frequency that is not a positive finite number gives a NaN column (the reference: NaN for 0 and NaN).
  *   vh_out      (n_prof, n_freq) row-major
  * Limits: n_alt <= 1400 (a profile's bottomside is held in LDS), n_freq <= 2^20, n_points >= 1.
  */
@@ -230,7 +248,8 @@ int prhf_snell_spherical_f64(prhf_ctx* ctx, const double* freq_hz, const double*
  * profile 0), ray_group[r] in [0, n_groups), elevation_deg[r].  geometry 0: flat Earth (the four controls are
  * ignored), 1: spherical Earth.  Outputs, paths, flags and errors as for the per-ray calls; the results are bit
  * for bit those of the per-ray calls on the same rays.  PRHF_EINVAL when the level table
- * (n_groups x (n_alt + 1) x 16 bytes) would exceed 4 GiB.
+ * (n_groups x (n_alt + 1) x 16 bytes) would exceed 4 GiB, and - checked on the host for host buffers, by the kernel
+ * for device-resident arrays (reported at the synchronisation) - when a ray_group or a profile index is out of range.
  */
 int prhf_snell_fan_f64(prhf_ctx* ctx, int32_t geometry, const double* group_freq_hz,
                        const int64_t* group_profile_index, int64_t n_groups, const int64_t* ray_group,

@@ -407,6 +407,22 @@ def gen_residual(lib):
             g11[f"{name}_edp"] = np.array(seen)
             print("G11", name, mode, "rows", len(rows), "NaN residuals", int(np.isnan(np.array(rows)).sum()),
                   "escaping obs", int(np.isnan(vh_obs).sum()), flush=True)
+            if mode == "O":
+                # the modeled traces behind those rows and their noise floors: the REFERENCE re-run NOISE_RUNS times on
+                # every candidate EDP with +-1 ulp on every input (noise_floor above), and - made with the pinned
+                # oracle, like G12 - the response to +-1 ulp in sin / cos / YT**4 / YT**3
+                from oracle import vfo_numpy as orc
+                edps = np.array(seen)
+                pairs = [noise_floor(lib, f_in, edp, b_mag, b_psi, alt, "O", n_points, seed=1100 + 13 * k)
+                         for k, edp in enumerate(edps)]
+                g11[f"{name}_O_vh_model"] = np.array([p[0] for p in pairs])
+                g11[f"{name}_O_noise"] = np.array([p[1] for p in pairs])
+                g11[f"{name}_O_noise_rounding"] = np.array(
+                    [orc.rounding_noise(f_in, edp, b_mag, b_psi, alt, "O", n_points, runs=NOISE_RUNS, seed=k)
+                     for k, edp in enumerate(edps)])
+                fin = np.isfinite(g11[f"{name}_O_vh_model"])
+                print("G11", name, "O noise > 1e-6 at", int((g11[f"{name}_O_noise"][fin] > 1e-6).sum()), "of", int(fin.sum()),
+                      "; rounding noise > 1e-6 at", int((g11[f"{name}_O_noise_rounding"][fin] > 1e-6).sum()), flush=True)
         for k, v in (("alt", alt), ("freq", f_in), ("bmag", b_mag), ("bpsi", b_psi)):
             g11[f"{name}_{k}"] = v
     g11["cases"] = np.array(sorted(cases))

@@ -18,7 +18,7 @@ OK, EINVAL, ENEGDEN, EPEAK0, EHIP, ENOMEM = 0, -1, -2, -3, -4, -5
 MODE_O, MODE_X = 0, 1
 FLAG_DEVICE_PTRS, FLAG_ASYNC, FLAG_GRID_STABLE, FLAG_SHARED_FIELD = 0x1, 0x2, 0x4, 0x8
 MATH_FAITHFUL, MATH_FAST, MATH_AUTO = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 
@@ -43,6 +43,7 @@ _PROTOTYPES = {
     "prhf_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "prhf_ctx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "prhf_ctx_set_math": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "prhf_ctx_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]),
     "prhf_vfo_batch_f64": (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
@@ -170,6 +171,9 @@ class Context:
         self._h = ctypes.c_void_p()
         raise_for(self._lib.prhf_ctx_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
+        # what the library was last told, so that the per-call setters cost a comparison, not a foreign call
+        self._math = None
+        self._stream = (0, False)          # (handle, borrowed): the context starts on its own stream
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -185,10 +189,22 @@ class Context:
     def set_stream(self, stream_ptr, borrow=True):
         """Launch on the caller's stream (``stream_ptr`` 0 = the legacy default stream) or, with
         ``borrow=False``, on the context's own stream."""
+        want = (int(stream_ptr or 0), bool(borrow)) if borrow else (0, False)
+        if want == self._stream:
+            return
         raise_for(self._lib.prhf_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None), 1 if borrow else 0))
+        self._stream = want
 
     def set_math(self, level):
-        raise_for(self._lib.prhf_ctx_set_math(self._h, int(level)))
+        level = int(level)
+        if level == self._math:
+            return
+        raise_for(self._lib.prhf_ctx_set_math(self._h, level))
+        self._math = level
+
+    def set_option(self, name, value):
+        """A launch-shaping or arithmetic setting of this context (include/prhf.h, prhf_ctx_set_option)."""
+        raise_for(self._lib.prhf_ctx_set_option(self._h, str(name).encode(), float(value)))
 
     def vfo_batch(self, freq, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride, alt_stride,
                   mult, n_points, mode, out, flags):

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,22 +39,46 @@ int fail(int code, const char* fmt, ...) {
             return fail(PRHF_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-long long kTargetWaves = 4096;             // waves resident at two 8-wave workgroups per CU (PRHF_TARGET_WAVES overrides)
 constexpr size_t kPackBytes = 1u << 20;
-int kLeanMinPoints = 65;                   // PRHF_LEAN_MIN_POINTS: shorter grids skip the pair table and the main loop
-double kWellConditioned = 1e-5;           // PRHF_WELL_CONDITIONED (experiments);  // hybrid O mode reproduces the reference to 1e-10
-double kThreadScanMinWork = 0.0;          // PRHF_THREAD_SCAN_MIN: n_freq x n_points from which X mode scans per thread (A/B knob)
-int kTailGroupMinPoints = 81;             // PRHF_TAIL_GROUP_MIN / _MAX: grids of this many points take four frequencies per item
-int kTailGroupMaxPoints = 1000;           // (beyond ~1000 points more than 16 of them are ill conditioned: nothing to share)
-int kNoCandidates = 0;                    // PRHF_NO_CANDIDATES=1: no per-profile candidate list (A/B runs)
-int kPersistent = 1;                       // PRHF_PERSISTENT=0: one workgroup per block, hardware dispatch order
-double kTailRounds = 1.0;                  // PRHF_TAIL_ROUNDS
-int kSplitMinPoints = 1024;                // PRHF_SPLIT_MIN_POINTS
-int kSplitFewProfiles = 1;                 // PRHF_SPLIT_FEW_PROFILES=0: one workgroup per profile whatever their number
-int kTailBpp = 4;                          // PRHF_TAIL_BPP (1 disables the tail refinement)
-int kShortKernel = 1;                      // PRHF_SHORT_KERNEL=0: short O-mode grids stay in the general kernel (A/B runs)
-int kShortConcurrent = 1;                  // PRHF_SHORT_CONCURRENT=0: short-grid and general launch of a mixed list one after the other
-int kShortQueueFixed = 0;                  // PRHF_SHORT_QUEUE=n: the short-grid kernel's queue holds exactly n entries (tests)
+
+// Launch-shaping and arithmetic settings of one context (prhf_ctx_set_option).  The defaults are
+// the measured best; tests and A/B runs change them per context.  Only a -DPRHF_DIAG build reads them from the
+// environment as well (PRHF_<NAME>, at context creation).
+struct Knobs {
+    double target_waves = 4096;        // waves resident at two 8-wave workgroups per CU: few-pair launches are chunked up to this
+    double lean_min_points = 65;       // shorter grids skip the pair table and the main loop
+    double well_conditioned = 1e-5;    // default O-mode arithmetic: the reference's operation order where 1 - X <= this
+    double thread_scan_min = 0.0;      // n_freq x n_points from which X mode settles reflection heights per thread
+    double no_candidates = 0;          // 1: no per-profile candidate list, every frequency is a work item
+    double persistent = 1;             // 0: one workgroup per block, hardware dispatch order
+    double tail_rounds = 1.0;          // resident rounds of workgroups at the end of a long slice that are cut finer
+    double tail_bpp = 4;               // ... into this many workgroups per profile (1: no tail refinement)
+    double split_min_points = 1024;    // few-profile slices are cut into several workgroups per profile from this grid size
+    double split_few_profiles = 1;     // 0: one workgroup per profile whatever their number
+    double short_kernel = 1;           // 0: short O-mode grids stay in the general kernel
+    double short_concurrent = 1;       // 0: short-grid and general launch of a mixed list one after the other
+    double short_queue = 0;            // > 0: the short-grid kernel's queue holds exactly this many entries (tests)
+};
+struct KnobName {
+    const char* name;
+    double Knobs::*field;
+    double lo, hi;
+};
+const KnobName kKnobNames[] = {
+    {"target_waves", &Knobs::target_waves, 64, 1e9},
+    {"lean_min_points", &Knobs::lean_min_points, 2, 1e9},
+    {"well_conditioned", &Knobs::well_conditioned, 0, 1},
+    {"thread_scan_min", &Knobs::thread_scan_min, 0, 1e300},
+    {"no_candidates", &Knobs::no_candidates, 0, 1},
+    {"persistent", &Knobs::persistent, 0, 1},
+    {"tail_rounds", &Knobs::tail_rounds, 0, 1e6},
+    {"tail_bpp", &Knobs::tail_bpp, 1, 64},
+    {"split_min_points", &Knobs::split_min_points, 1, 1e9},
+    {"split_few_profiles", &Knobs::split_few_profiles, 0, 1},
+    {"short_kernel", &Knobs::short_kernel, 0, 1},
+    {"short_concurrent", &Knobs::short_concurrent, 0, 1},
+    {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
+};
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
@@ -110,12 +135,16 @@ struct prhf_ctx {
     static constexpr int kTimingRing = 64;
     hipEvent_t ring0[kTimingRing] = {}, ring1[kTimingRing] = {};
     unsigned long long n_timed = 0;    // launches timed so far
-    int slot = 0;                      // ring slot of the launch being enqueued / enqueued last
+    int slot = 0;                      // ring slot of the last launch that was enqueued completely
+    int pending = 0;                   // ring slot of the launch being enqueued: published by mark_timed() only, so that
+                                       // a launch that fails half way leaves `slot` on the last good pair of events
     bool timed = false;
-    hipEvent_t begin_ev() { slot = (int)(n_timed % kTimingRing); return ring0[slot]; }
+    hipEvent_t begin_ev() { pending = (int)(n_timed % kTimingRing); return ring0[pending]; }
+    hipEvent_t pending_end_ev() const { return ring1[pending]; }
     hipEvent_t end_ev() const { return ring1[slot]; }
-    void mark_timed() { ++n_timed; timed = true; }
+    void mark_timed() { slot = pending; ++n_timed; timed = true; }
     int math = PRHF_MATH_AUTO;
+    Knobs knobs;
     int cu_count = 256;
     DevBuf arena;     // staged host inputs + output
     DevBuf partial;   // chunk sums
@@ -126,10 +155,12 @@ struct prhf_ctx {
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
-    unsigned* d_status = nullptr;   // [0] PRHF_STATUS_* bits, [1..3] block queues of persistent launches (general,
-                                    // short-grid, its follow-up)
-    unsigned* h_status = nullptr;   // pinned
-    double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece
+    unsigned* d_status = nullptr;   // device words [1..3]: block queues of persistent launches (general, short-grid, its
+                                    // follow-up); [0] unused
+    unsigned* h_status = nullptr;   // PRHF_STATUS_WORDS words of pinned host memory mapped into the device: word b = status
+    unsigned* h_status_dev = nullptr;   // bit b (post_status) - nothing to copy back or reset on the device; its device address
+    double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece; its upper
+    double* h_pack_dev = nullptr;   // half, mapped into the device (h_pack_dev), takes a small result straight from the kernel
     unsigned long long* d_words = nullptr;   // 2 words: nanmax|Y| bits, any-not-NaN
     unsigned long long* h_words = nullptr;   // pinned
     bool status_pending = false;
@@ -156,7 +187,12 @@ int ensure(prhf_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 // Decompose one slice into wave-sized items and blocks ("Launch geometry").
-void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
+void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots, const Knobs& kn) {
+    const long long kTargetWaves = (long long)kn.target_waves;
+    const bool kSplitFewProfiles = kn.split_few_profiles != 0;
+    const long long kSplitMinPoints = (long long)kn.split_min_points;
+    const double kTailRounds = kn.tail_rounds;
+    const int kTailBpp = (int)kn.tail_bpp;
     const long long P = s.prof_end - s.prof_begin;
     const long long pairs = P * n_freq;
     const long long N = s.n_points;
@@ -168,10 +204,7 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots) {
     }
     s.chunks = (int)chunks;
     s.chunk_len = (int)chunk_len;
-    // short grids in the default O-mode arithmetic: four frequencies per item (run_items_tail16)
-    s.group = (s.tier == 0 && s.well_conditioned < 1.0 && s.lean && chunks == 1 && N >= kTailGroupMinPoints &&
-               N <= kTailGroupMaxPoints) ? 4 : 1;
-    const long long items = s.group == 4 ? (n_freq + 3) / 4 : n_freq * chunks;
+    const long long items = n_freq * chunks;
     long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
                                                                  std::max<long long>(P, 1)));
     s.blocks_per_prof = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -207,7 +240,10 @@ struct Residual {
 int status_to_code(unsigned bits) {
     if (bits & PRHF_STATUS_PEAK0)
         return fail(PRHF_EPEAK0, "density peak at index 0: no bottomside levels below the peak");
+    if (bits & PRHF_STATUS_NANINPUT)
+        return fail(PRHF_EINVAL, "NaN in a profile (den or alt anywhere in the column, bmag or bpsi below the density peak)");
     if (bits & PRHF_STATUS_NEGDEN) return fail(PRHF_ENEGDEN, "Density must be non-negative");
+    if (bits & PRHF_STATUS_BADGROUP) return fail(PRHF_EINVAL, "ray_group outside [0, n_groups)");
     if (bits & PRHF_STATUS_BADINDEX) return fail(PRHF_EINVAL, "profile_index outside [0, n_prof)");
     return PRHF_OK;
 }
@@ -235,15 +271,26 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     const bool shared_field = (flags & PRHF_FLAG_SHARED_FIELD) != 0;
     if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
         return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
-    // Host buffers: a sounder frequency must be a positive finite number (the reference divides by it and returns
-    // NaN or garbage silently for 0, negative and NaN frequencies; device-resident frequencies are the caller's).
+    // (A sounder frequency that is not a positive finite number gives a NaN column, host and device buffers alike:
+    //  freq_table_kernel / pair_freq.  The reference returns NaN for 0 and NaN, and something meaningless for f < 0.)
+    // The stretched grid must not decrease (smooth_nonuniform_grid never does): the top-segment search of the main
+    // loop relies on it.  Checked here for host buffers; device-resident grids are the caller's.
     if (!dev)
-        for (int64_t i = 0; i < n_freq; ++i)
-            if (!(freq[i] > 0.0) || !std::isfinite(freq[i]))
-                return fail(PRHF_EINVAL, "freq[%lld] must be a positive finite number (MHz)", (long long)i);
+        for (int32_t g = 0; g < n_segs; ++g)
+            if (segs[g].mult_offset >= 0 && segs[g].n_points >= 1 && segs[g].mult_offset + segs[g].n_points <= mult_len)
+                for (int64_t i = segs[g].mult_offset + 1; i < segs[g].mult_offset + segs[g].n_points; ++i)
+                    if (mult[i] < mult[i - 1])
+                        return fail(PRHF_EINVAL, "multiplier[%lld] decreases: the stretched grid must be non-decreasing",
+                                    (long long)i);
 
     ENTER_DEVICE(c->device);
 
+    const Knobs& kn = c->knobs;
+    const double kWellConditioned = kn.well_conditioned, kThreadScanMinWork = kn.thread_scan_min;
+    const int kLeanMinPoints = (int)kn.lean_min_points, kNoCandidates = kn.no_candidates != 0;
+    const bool kPersistent = kn.persistent != 0, kShortKernel = kn.short_kernel != 0;
+    const bool kShortConcurrent = kn.short_concurrent != 0;
+    const int kShortQueueFixed = (int)kn.short_queue;
     const int n_user_segs = n_segs;
     prhf::KArgs a;
     std::memset(&a, 0, sizeof a);
@@ -301,7 +348,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                   table_is_cheap) ? 1 : 0;
         want_pairs = want_pairs || s.lean != 0;
         s.thread_scan = ((double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
-        plan_slice(s, n_freq, wg_slots);
+        plan_slice(s, n_freq, wg_slots, kn);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
     // (a.seg[i] was filled for every slice; now the short-grid slices move out and the others close ranks)
@@ -309,19 +356,17 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         int kept = 0;
         for (int i = 0; i < n_segs; ++i) {
             const prhf::SegDev& s = a.seg[i];
-            // the short-grid kernel reads the per-frequency table (launches of >= 4096 pairs), settles the
-            // reflection heights per thread (n_freq <= n_alt) and lists at most PRHF_MAX_CAND frequencies
+            // the short-grid kernel reads the per-frequency table (launches of >= 4096 pairs) and lists at most
+            // PRHF_MAX_CAND frequencies per profile
             const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && s.lean && s.chunks == 1 &&
                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
-                                  n_freq <= n_alt && n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 &&
-                                  !kNoCandidates && short_queue > 0;
+                                  n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && short_queue > 0;
             if (is_short) {
                 prhf::SegDev& t = short_seg[n_short++];
                 t = s;
                 t.blocks_per_prof = 1;
                 t.tail_prof = t.prof_end - t.prof_begin;
                 t.tail_bpp = 1;
-                t.group = 1;                       // (the follow-up launch of the general kernel: one pair per item)
                 t.prio = 0;
             } else {
                 if (kept != i) a.seg[kept] = a.seg[i];
@@ -362,10 +407,11 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     if ((rc = ensure(c, c->altmin, (size_t)altmin_elems * 8)) != PRHF_OK) return rc;
     a.partial = static_cast<double*>(c->partial.p);
     a.altmin = static_cast<double*>(c->altmin.p);
-    a.status = c->d_status;
+    a.status = c->h_status_dev;
 
     const size_t row_bytes = (size_t)n_alt * 8;
     double* d_out = nullptr;
+    bool out_direct = false;
     const size_t out_elems = (size_t)out_rows * (size_t)n_freq;
     if (dev) {
         a.freq = freq; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = mult;
@@ -432,6 +478,16 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         // rows that no segment covers must come back as NaN, not as whatever the arena held (all-ones bytes = NaN)
         long long covered = 0;
         for (int i = 0; i < n_user_segs; ++i) covered += segs[i].prof_end - segs[i].prof_begin;
+        // A small result (the reference's usual call: one profile) goes straight from the kernel into pinned host
+        // memory - the upper half of the pack buffer, which the device sees - instead of into the arena and through
+        // a copy of its own: one runtime call and one DMA round trip less per call.
+        out_direct = out && out_elems && !post && c->h_pack && out_elems * 8 <= kPackBytes / 4 &&
+                     in_elems * 8 <= kPackBytes / 2;
+        if (out_direct) {
+            a.out = c->h_pack_dev + kPackBytes / 16;           // doubles: byte offset kPackBytes / 2
+            if (covered < out_rows) std::memset(c->h_pack + kPackBytes / 16, 0xFF, out_elems * 8);
+            covered = out_rows;                                // (no device-side fill)
+        }
         if (covered < out_rows && out_elems) HIP_TRY(hipMemsetAsync(d_out, 0xFF, out_elems * 8, c->stream));
         a.prof_stride = n_alt;
         a.field_stride = shared_field ? 0 : n_alt;
@@ -487,7 +543,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 #endif
     a.n_blocks = blocks;
     a.no_candidates = kNoCandidates;
-    HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 3 * sizeof(unsigned), c->stream));     // the launches' block queues
+    if (n_short > 0 || (kPersistent && blocks > wg_slots))
+        HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 3 * sizeof(unsigned), c->stream));     // the launches' block queues
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
     // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
@@ -585,16 +642,18 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 #endif
     if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     c->status_pending = true;
 
     // small results come back through the pinned buffer too (its upper half; the inputs of a call this small
     // fit the lower one) and are handed over after the synchronisation below
-    const bool out_via_pack = !dev && out && out_elems && c->h_pack && out_elems * 8 <= kPackBytes / 4 &&
+    const bool out_via_pack = !out_direct && !dev && out && out_elems && c->h_pack && out_elems * 8 <= kPackBytes / 4 &&
                               (size_t)(d_out - static_cast<double*>(c->arena.p)) * 8 <= kPackBytes / 2;
     double* h_out = c->h_pack ? c->h_pack + kPackBytes / 16 : nullptr;       // doubles: byte offset kPackBytes / 2
-    if (out_via_pack)
+    if (out_direct) {
+        // (written by the kernel itself)
+    } else if (out_via_pack)
         HIP_TRY(hipMemcpyAsync(h_out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
     else if (!dev && out_elems && out)
         HIP_TRY(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, c->stream));
@@ -606,7 +665,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
     if (flags & PRHF_FLAG_ASYNC) return PRHF_OK;
     rc = prhf_sync(c);
-    if (out_via_pack) std::memcpy(out, h_out, out_elems * 8);
+    if (out_via_pack || out_direct) std::memcpy(out, h_out, out_elems * 8);
     return rc;
 }
 
@@ -627,24 +686,6 @@ int prhf_device_count(int* n) {
 
 int prhf_ctx_create(int device, prhf_ctx** out) {
     if (!out) return fail(PRHF_EINVAL, "null pointer");
-    if (const char* tw = std::getenv("PRHF_TARGET_WAVES")) {      // tuning knob, see DESIGN.md 4.1
-        const long long v = std::atoll(tw);
-        if (v >= 64) kTargetWaves = v;
-    }
-    if (const char* ps = std::getenv("PRHF_PERSISTENT")) kPersistent = std::atoi(ps) != 0;
-    if (const char* nc = std::getenv("PRHF_NO_CANDIDATES")) kNoCandidates = std::atoi(nc) != 0;
-    if (const char* wc = std::getenv("PRHF_WELL_CONDITIONED")) kWellConditioned = std::atof(wc);
-    if (const char* ts = std::getenv("PRHF_THREAD_SCAN_MIN")) kThreadScanMinWork = std::atof(ts);
-    if (const char* lm = std::getenv("PRHF_LEAN_MIN_POINTS")) kLeanMinPoints = std::max(2, std::atoi(lm));
-    if (const char* g0 = std::getenv("PRHF_TAIL_GROUP_MIN")) kTailGroupMinPoints = std::max(81, std::atoi(g0));
-    if (const char* g1 = std::getenv("PRHF_TAIL_GROUP_MAX")) kTailGroupMaxPoints = std::atoi(g1);
-    if (const char* tr = std::getenv("PRHF_TAIL_ROUNDS")) kTailRounds = std::max(0.0, std::atof(tr));
-    if (const char* sf = std::getenv("PRHF_SPLIT_FEW_PROFILES")) kSplitFewProfiles = std::atoi(sf);
-    if (const char* sm = std::getenv("PRHF_SPLIT_MIN_POINTS")) kSplitMinPoints = std::atoi(sm);
-    if (const char* tb = std::getenv("PRHF_TAIL_BPP")) kTailBpp = std::max(1, std::atoi(tb));
-    if (const char* sk = std::getenv("PRHF_SHORT_KERNEL")) kShortKernel = std::atoi(sk);
-    if (const char* sq = std::getenv("PRHF_SHORT_QUEUE")) kShortQueueFixed = std::atoi(sq);
-    if (const char* sc = std::getenv("PRHF_SHORT_CONCURRENT")) kShortConcurrent = std::atoi(sc);
     *out = nullptr;
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -661,10 +702,13 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 4 * sizeof(unsigned))) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), sizeof(unsigned), hipHostMallocDefault)) !=
-            hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), PRHF_STATUS_WORDS * sizeof(unsigned),
+                           hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_status_dev), c->h_status, 0)) != hipSuccess ||
         (e = hipMemset(c->d_status, 0, 4 * sizeof(unsigned))) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocMapped | hipHostMallocCoherent)) !=
+            hipSuccess ||
+        (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_pack_dev), c->h_pack, 0)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_words), 2 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 2 * sizeof(unsigned long long),
                            hipHostMallocDefault)) != hipSuccess ||
@@ -673,6 +717,15 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         return fail(PRHF_EHIP, "context setup failed: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    std::memset(c->h_status, 0, PRHF_STATUS_WORDS * sizeof(unsigned));
+#ifdef PRHF_DIAG
+    // diagnostics build only: PRHF_<OPTION NAME IN CAPITALS>=value presets the options of every new context
+    for (const KnobName& k : kKnobNames) {
+        std::string env = "PRHF_";
+        for (const char* p = k.name; *p; ++p) env += (char)std::toupper((unsigned char)*p);
+        if (const char* v = std::getenv(env.c_str())) c->knobs.*(k.field) = std::min(k.hi, std::max(k.lo, std::atof(v)));
+    }
+#endif
     (void)hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device);
     if (c->cu_count < 1) c->cu_count = 256;
     *out = c;
@@ -719,6 +772,18 @@ int prhf_ctx_set_stream(prhf_ctx* c, void* hip_stream, int32_t borrow) {
     if (c->timed) HIP_TRY(hipStreamWaitEvent(next, c->end_ev(), 0));
     c->stream = next;
     return PRHF_OK;
+}
+
+int prhf_ctx_set_option(prhf_ctx* c, const char* name, double value) {
+    if (!c || !name) return fail(PRHF_EINVAL, "null pointer");
+    for (const KnobName& k : kKnobNames)
+        if (std::strcmp(k.name, name) == 0) {
+            if (!(value >= k.lo && value <= k.hi))
+                return fail(PRHF_EINVAL, "option %s: %g outside [%g, %g]", name, value, k.lo, k.hi);
+            c->knobs.*(k.field) = value;
+            return PRHF_OK;
+        }
+    return fail(PRHF_EINVAL, "unknown option '%s'", name);
 }
 
 int prhf_ctx_set_math(prhf_ctx* c, int level) {
@@ -795,7 +860,7 @@ int prhf_mu_mup_f64(prhf_ctx* c, const double* X, const double* Y, const double*
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_mu_mup(dX, dY, dP, n, mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
                                 c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dMu, dMup, c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(mu_out, dMu, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -832,7 +897,7 @@ int prhf_find_vh_f64(prhf_ctx* c, const double* X, const double* Y, const double
     HIP_TRY(prhf::launch_find_vh(dX, dY, dP, dD, n_rows, n_cols, alt_min,
                                  mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X,
                                  c->math == PRHF_MATH_FAST ? 1 : 0, c->d_words, c->h_words, dV, c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     if (!dev) HIP_TRY(hipMemcpyAsync(vh_out, dV, (size_t)n_rows * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -858,7 +923,7 @@ int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const do
     std::memset(&a, 0, sizeof a);
     a.n_freq = n_freq; a.n_alt = n_alt; a.n_points = n_points;
     a.mode = mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
-    a.status = c->d_status;
+    a.status = c->h_status_dev;
     double* base = nullptr;
     if (dev) {
         a.freq_hz = freq_hz; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = multiplier;
@@ -890,7 +955,7 @@ int prhf_regrid_f64(prhf_ctx* c, const double* freq_hz, int64_t n_freq, const do
     }
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_regrid(a, prhf::lds_bytes_for(n_alt), c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     c->status_pending = true;
     if (!dev) {
@@ -930,7 +995,7 @@ int prhf_residual_f64(prhf_ctx* c, const double* vh_model, const double* vh_obs,
     }
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_residual(dM, dO, n_prof, (int)n_freq, dR, dC, c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     if (!dev) {
         if (residual_out) HIP_TRY(hipMemcpyAsync(residual_out, dR, pf * 8, hipMemcpyDeviceToHost, c->stream));
@@ -991,7 +1056,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     a.dz_target_km = geo.dz_target_km;
     a.apex_boost = geo.apex_boost;
     a.max_substeps = geo.max_substeps;
-    a.status = c->d_status;
+    a.status = c->h_status_dev;
     const size_t prof_elems = (size_t)n_prof * (size_t)n_alt;
     const size_t alt_elems = alt_stride_elems ? prof_elems : (size_t)n_alt;
     const size_t path_elems = path_x ? (size_t)n_rays * (size_t)path_stride : 0;
@@ -1053,7 +1118,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     }
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_snell(a, c->stream));
-    HIP_TRY(hipEventRecord(c->end_ev(), c->stream));
+    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     c->status_pending = true;
     if (!dev) {
@@ -1119,14 +1184,15 @@ int prhf_occupancy(prhf_ctx* c, int64_t n_alt, int32_t math, int32_t* workgroups
 int prhf_sync(prhf_ctx* c) {
     if (!c) return fail(PRHF_EINVAL, "null context");
     ENTER_DEVICE(c->device);
-    if (c->status_pending) {
-        HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(unsigned), c->stream));
-    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->status_pending) {
         c->status_pending = false;
-        return status_to_code(*c->h_status);
+        unsigned bits = 0;
+        for (int b = 0; b < PRHF_STATUS_WORDS; ++b) {
+            if (reinterpret_cast<volatile unsigned*>(c->h_status)[b]) bits |= 1u << b;
+            c->h_status[b] = 0;
+        }
+        return status_to_code(bits);
     }
     return PRHF_OK;
 }

@@ -12,6 +12,9 @@
 #define PRHF_STATUS_NEGDEN 0x1
 #define PRHF_STATUS_PEAK0  0x2
 #define PRHF_STATUS_BADINDEX 0x4    // a ray's profile_index outside [0, n_prof) (tracers)
+#define PRHF_STATUS_WORDS 8         // one word of host-visible memory per status bit (post_status)
+#define PRHF_STATUS_NANINPUT 0x10   // NaN in a profile's density or altitude column, or in |B| / psi below its peak
+#define PRHF_STATUS_BADGROUP 0x8    // a ray's ray_group outside [0, n_groups) (grouped tracer launch)
 
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
@@ -57,8 +60,6 @@ struct SegDev {
     double well_conditioned;
     int lean;                        // this slice uses the main loop (and KArgs::pairs); decided per slice so that a
                                      // slice gets the same arithmetic alone and inside a mixed launch
-    int group;                       // frequencies per work item: 1, or 4 on short grids in the default O-mode
-                                     // arithmetic (run_items_tail16: four 16-point tails share one wave-iteration)
     int prio;                        // wave priority (0..3) of this slice's workgroups in a mixed launch: see vfo_kernel
     int thread_scan;                 // X mode: reflection heights settled one frequency per thread while the candidate
                                      // list is made (on by default; PRHF_THREAD_SCAN_MIN turns it off for A/B runs.
@@ -102,7 +103,7 @@ inline size_t lds_bytes_for(long long n_alt) {
 // LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
 // nodes, then `queue` entries of 8 bytes (a profile with K < n_alt levels adds its unused nodes to the queue).
 inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq) {
-    const size_t b = (size_t)n_alt * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_BLOCK_THREADS / 64) * 16 * 12 +
+    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_BLOCK_THREADS / 64) * 16 * 12 +
                      PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 4 + (size_t)n_freq * 2;
     return (b + 15) & ~(size_t)15;
 }

@@ -1,7 +1,7 @@
 // prhf_kernels.hip - fused vertical-ionogram forward operator for gfx950 (MI355X, CDNA4).
 //
 // One wavefront (64 lanes) evaluates one (profile, frequency) pair - or one chunk of its stretched grid when
-// few pairs are submitted, or four pairs on short O-mode grids.  A workgroup shares one profile: its bottomside
+// few pairs are submitted.  (Short O-mode grids have a kernel of their own: prhf_short.inc.)  A workgroup shares one profile: its bottomside
 // columns are staged once into LDS as 96-byte nodes (stage_profile), so that every grid point costs at most one
 // LDS round trip and no HBM traffic.  Per pair:
 //   S3-S6  reflection height (reflection_height): X mode - lanes stride over the levels, first level with
@@ -40,6 +40,8 @@ constexpr double kUnmagTol = 1e-12;                 // library.py:163
 constexpr double kLightKmS = 299792.458;            // library.py:70
 constexpr double kPolyAngle = 3e-4;                 // rad per segment below which the sin^2 cubic errs < 3e-15
 constexpr double kQuadAngle = 4e-5;                 // ... and below which its economised quadratic errs < 1.4e-15
+constexpr double kTrigAngle = 0.05;                 // rad per segment up to which the angle is rotated from the node's
+                                                    // cos 2psi / sin 2psi by a short Taylor pair (|2 theta| <= 0.1: 3e-17)
 constexpr double kLinTol = 1e-10;                   // a segment's quadratic term may be economised away when that costs
                                                     // < 1e-10 in sin^2 psi: an offset of 4e-11 everywhere moves a virtual
                                                     // height by <= 1.6e-11 (measured), an equioscillating one by less
@@ -62,6 +64,14 @@ struct __attribute__((aligned(16))) Node {
 static_assert(sizeof(Node) == PRHF_NODE_BYTES, "node size");
 
 __device__ __forceinline__ double qnan() { return __builtin_nan(""); }
+
+// Data errors are reported through a few words of pinned HOST memory that the device sees (prhf_api.cpp): word b is
+// set to 1 for status bit b.  Plain stores of the same value - no atomics over the bus, nothing to copy back or to
+// reset on the device: the host reads the words after the synchronisation and clears them itself.
+__device__ __forceinline__ void post_status(unsigned* status, unsigned bits) {
+    for (int b = 0; b < PRHF_STATUS_WORDS; ++b)
+        if (bits & (1u << b)) __hip_atomic_store(status + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Cross-lane exchanges without address registers.  __shfl_xor / __shfl_up compile to ds_bpermute_b32 with the
 // source lane in a VGPR; inside the persistent loop the compiler hoists those twelve lane patterns out of the
@@ -365,7 +375,8 @@ struct BlockInfo {
     int bad;          // PRHF_STATUS_* bits for this profile
     int unmag;        // isotropic branch
     int uniform;      // altitude grid is uniform below the peak
-    int poly_angle;   // every segment has a 2 cos^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too); 0: some use sin()
+    int poly_angle;   // every segment has a 2 cos^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too);
+                      // 4: every segment in rotation form (some turn the field by 3e-4 .. 0.05 rad); 0: some need sin() per point
     int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
     const double* heights;   // O mode with a candidate list: reflection height of every entry (they all reflect); else null
     double a0;        // alt[0]
@@ -374,12 +385,12 @@ struct BlockInfo {
 };
 
 // Per-profile scalars that are read once per pair only live in LDS (in the reduction scratch, behind its
-// 9 rows) rather than in SGPRs: the main loop needs every scalar register it can get.
+// 10 rows) rather than in SGPRs: the main loop needs every scalar register it can get.
 enum { kKeepAltMin = 0,     // min over the whole altitude column (:507)
        kKeepPf2Max = 1,     // max f_N^2 over the bottomside levels
        kKeepGbMax = 2 };    // g_p max|B| over the bottomside levels
 template <int THREADS>
-__device__ __forceinline__ const double* kept_scalars(const double* red) { return red + 9 * (THREADS / 64); }
+__device__ __forceinline__ const double* kept_scalars(const double* red) { return red + 10 * (THREADS / 64); }
 
 constexpr int kHintBuckets = PRHF_HINT_BUCKETS;
 
@@ -405,19 +416,21 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                                                    unsigned short* hint, double* red) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
-    static_assert(9 * W + 3 <= PRHF_RED_DOUBLES, "reduction scratch too small");
+    static_assert(10 * W + 3 <= PRHF_RED_DOUBLES, "reduction scratch too small");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // red rows of W doubles: 0 peak value, 1 peak index, 2 alt min, 3 freq min,
     //                        4 |B| max, 5 negative density, 6 max angle step, 7 non-uniform grid,
-    //                        8 f_N^2 max below the peak
+    //                        8 f_N^2 max below the peak, 9 NaN in the density or altitude column
     // ---- phase 1: first-occurrence argmax of density, min altitude, min frequency ---------
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     double amin = __builtin_inf();
-    for (int i = tid; i < n_alt; i += THREADS) {
-        const double v = den[i];
+    int nan_in = 0;                                // NaN inputs are an error (PRHF_STATUS_NANINPUT): np.argmax / np.interp
+    for (int i = tid; i < n_alt; i += THREADS) {   // would propagate them into every frequency of the profile
+        const double v = den[i], al = alt[i];
         if (v > bv) { bv = v; bi = i; }
-        amin = fmin(amin, alt[i]);
+        amin = fmin(amin, al);
+        nan_in |= (v != v || al != al) ? 1 : 0;
     }
     double fm = __builtin_inf();
     for (int i = tid; i < n_freq; i += THREADS) fm = fmin(fm, fabs(freq[i]));
@@ -440,17 +453,20 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     }
     amin = wave_min(amin);
     fm = wave_min(fm);
+    nan_in = __any(nan_in) ? 1 : 0;
     if (lane == 0) {
         red[wave] = bv;
         red[W + wave] = (double)bi;
         red[2 * W + wave] = amin;
         red[3 * W + wave] = fm;
+        red[9 * W + wave] = (double)nan_in;
     }
     __syncthreads();
     bv = red[0];
     bi = (int)red[W];
     amin = red[2 * W];
     fm = red[3 * W];
+    nan_in = (int)red[9 * W];
 #pragma unroll
     for (int w = 1; w < W; ++w) {
         const double ov = red[w];
@@ -458,12 +474,13 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         amin = fmin(amin, red[2 * W + w]);
         fm = fmin(fm, red[3 * W + w]);
+        nan_in |= (int)red[9 * W + w];
     }
     PRHF_MARK(0);
     BlockInfo info;
     info.K = uniform((bi == 0x7fffffff) ? 0 : bi);      // library.py:371-375: levels [0, argmax)
     // every thread holds the same reduced value and writes it: a wave reads back what it wrote itself
-    red[9 * W + kKeepAltMin] = amin;
+    red[10 * W + kKeepAltMin] = amin;
     fm = uniform(fm);
     info.bad = 0;
     info.unmag = 0;
@@ -474,6 +491,11 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     info.inv_w = 0.0;
     info.inv_step = 0.0;
     const int K = info.K;
+    if (uniform(nan_in)) {
+        info.bad = PRHF_STATUS_NANINPUT;
+        info.K = 0;
+        return info;
+    }
     if (K == 0) {
         info.bad = PRHF_STATUS_PEAK0;
         return info;
@@ -481,7 +503,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
     const double step0 = (K > 1) ? alt[1] - alt[0] : 1.0;
     double bmax = 0.0, pmax = 0.0;
-    int neg = 0, ragged = 0, trig = 0, cubic = 0, quadratic = 0;
+    int neg = 0, ragged = 0, trig = 0, cubic = 0, quadratic = 0, steep = 0;
     for (int k = tid; k <= K; k += THREADS) {
         Node nd;
         if (k == K) {                              // sentinel: no abscissa is >= +inf
@@ -542,9 +564,11 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             }
             // stored as 2 cos^2(psi) = 2 - 2 sin^2(psi): the main loop wants Y_L^2 first (group_index_lean)
             nd.u0 = 2.0 - 2.0 * nd.u0; nd.u1 = -2.0 * nd.u1; nd.u2 = -2.0 * nd.u2; nd.u3 = -2.0 * nd.u3;
-        } else {                                   // this segment turns the field too far for the cubic
-            nd.u0 = p * kDegToRad; nd.u1 = spsi * kDegToRad; nd.u2 = 0.0; nd.u3 = qnan();
+        } else {                                   // this segment turns the field too far for the cubic:
+            nd.u0 = nd.u1 = nd.u2 = 0.0;           // u3 = NaN is the flag; the generic loop takes sin() of psi + spsi dz,
+            nd.u3 = qnan();                        // the main loop needs the rotation form below (whole profile)
             trig = 1;
+            steep |= (turn > kTrigAngle) ? 1 : 0;
         }
         nodes[k] = nd;
         const double fn = sqrt(d) * kPlasma;       // :96
@@ -553,13 +577,15 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         pmax = fmax(pmax, fn * fn);
         bmax = fmax(bmax, fabs(b));
         neg |= (d < 0.0) ? 1 : 0;
+        neg |= (b != b || p != p) ? 2 : 0;         // NaN in the field columns below the peak
     }
     bmax = wave_max(bmax);
     pmax = wave_max(pmax);
-    neg = __any(neg) ? 1 : 0;
+    neg = (__any(neg & 1) ? 1 : 0) | (__any(neg & 2) ? 2 : 0);
     ragged = __any(ragged) ? 1 : 0;
-    // 1: some segment needs sin(), 2: some segment keeps its cubic, 3: some keeps its quadratic, 0: all linear
-    trig = __any(trig) ? 1 : (__any(cubic) ? 2 : (__any(quadratic) ? 3 : 0));
+    // 5: some segment turns the field by more than kTrigAngle (sin() per point, generic loop), 1: some segment needs the
+    // rotation form, 2: some segment keeps its cubic, 3: some keeps its quadratic, 0: all linear
+    trig = __any(steep) ? 5 : (__any(trig) ? 1 : (__any(cubic) ? 2 : (__any(quadratic) ? 3 : 0)));
     if (lane == 0) {
         red[4 * W + wave] = bmax;
         red[5 * W + wave] = (double)neg;
@@ -579,23 +605,39 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         pmax = fmax(pmax, red[8 * W + w]);
         neg |= (int)red[5 * W + w];
         {
-            const int o = (int)red[6 * W + w];          // order of need: sin() 1 > cubic 2 > quadratic 3 > linear 0
-            trig = (trig == 1 || o == 1) ? 1 : ((trig == 2 || o == 2) ? 2 : ((trig == 3 || o == 3) ? 3 : 0));
+            const int o = (int)red[6 * W + w];          // order of need: sin() 5 > rotation 1 > cubic 2 > quadratic 3 > linear 0
+            trig = (trig == 5 || o == 5) ? 5
+                 : ((trig == 1 || o == 1) ? 1 : ((trig == 2 || o == 2) ? 2 : ((trig == 3 || o == 3) ? 3 : 0)));
         }
         ragged |= (int)red[7 * W + w];
     }
     bmax = uniform(bmax);
-    red[9 * W + kKeepPf2Max] = pmax;
-    red[9 * W + kKeepGbMax] = kGyro * bmax;
+    red[10 * W + kKeepPf2Max] = pmax;
+    red[10 * W + kKeepGbMax] = kGyro * bmax;
     neg = uniform(neg);
     trig = uniform(trig);
     ragged = uniform(ragged);
-    if (neg) info.bad = PRHF_STATUS_NEGDEN;        // library.py:93-94
+    if (neg & 1) info.bad = PRHF_STATUS_NEGDEN;    // library.py:93-94
+    if (neg & 2) info.bad = PRHF_STATUS_NANINPUT;
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
     info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
-    info.poly_angle = trig == 1 ? 0 : (trig == 2 ? 1 : (trig == 3 ? 2 : 3));
+    info.poly_angle = trig == 5 ? 0 : (trig == 1 ? 4 : (trig == 2 ? 1 : (trig == 3 ? 2 : 3)));
+    if (info.poly_angle == 4) {
+        // Rotation form for EVERY segment of this profile: 2 cos^2(psi_j + r x) = 1 + cos(2 psi_j) cos(theta) -
+        // sin(2 psi_j) sin(theta), theta = 2 r x: u0 = cos 2psi_j, u1 = 2 r [rad/km], u2 = sin 2psi_j (lean_step<POLY 4>).
+        // u3 stays / becomes NaN: the generic loop (tails, fallbacks) keeps taking sin() of the interpolated angle.
+        for (int k = tid; k < K; k += THREADS) {
+            double sp, cp;
+            prhf_cr::sincos_table(nodes[k].psi * kDegToRad, &sp, &cp);
+            nodes[k].u0 = (cp - sp) * (cp + sp);
+            nodes[k].u1 = 2.0 * (nodes[k].spsi * kDegToRad);
+            nodes[k].u2 = 2.0 * (sp * cp);
+            nodes[k].u3 = qnan();
+        }
+        __syncthreads();
+    }
     // ---- phase 3: segment lookup: closed form when uniform, else a hint table --------------
     const double a0 = uniform(nodes[0].alt);
     const double span = uniform(nodes[K - 1].alt) - a0;
@@ -679,7 +721,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             if (poly_angle || nd.u3 == nd.u3) {        // per segment; poly_angle: true for the whole profile
                 S2 = 1.0 - 0.5 * (nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3)));    // the nodes hold 2 cos^2
             } else {
-                const double sn = sin(nd.u0 + nd.u1 * dz);
+                const double sn = sin((nd.spsi * dz + nd.psi) * kDegToRad);
                 S2 = sn * sn;
             }
             index_fast<MODE>(X, Y2, S2, &mu, &mup);
@@ -736,42 +778,73 @@ __device__ __forceinline__ double group_index_lean(double den, double hY2, doubl
 // quadratic (u3 = 0, not read), 1 economised linear (u2 = 0 too, not read).
 // HINT: non-uniform altitude grid - kj is hint buckets per unit of m, the segment comes from the hint table
 // (last level at or below the bucket's left edge) plus a walk up the levels inside the bucket.
+// The monotone segment cursor of the HINT variant: the lane's current segment and the altitude of the level above it.
+// A lane's grid points come in ascending order (lean_loop_body), so its abscissae only grow and the segment index only
+// moves up: where no lane of the wave crosses a level - almost always, the stretched grid is much denser than the
+// levels - the step costs one compare and a ballot and no LDS read at all (a bucket lookup and a walk per point -
+// two dependent LDS round trips - made non-uniform altitude grids 1.5x slower than uniform ones).
+struct SegCursor {
+    int j;
+    double above;       // nodes[j + 1].alt; level K is a +inf sentinel, so a walk stops by itself
+};
+__device__ __forceinline__ double lds_alt(unsigned nodes_v, int j) {
+    typedef __attribute__((address_space(3))) const double* LdsDouble;
+    return *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
+}
+// np.interp's segment of abscissa z = m span + a0 from the hint table (last level at or below the bucket's left edge)
+// plus a walk up the levels inside the bucket: once per loop call and lane
+__device__ __forceinline__ SegCursor cursor_at(double m0, double span, double a0, double kj, unsigned nodes_v, unsigned hint_v) {
+#pragma clang fp contract(fast)
+    typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
+    SegCursor c;
+    // (a bucket < kHintBuckets: m <= 1 and kj < kHintBuckets, checked by the caller)
+    c.j = *(LdsU16)(uintptr_t)(hint_v + 2u * (unsigned)(int)(m0 * kj));
+    const double z = __builtin_fma(m0, span, a0);
+    c.above = lds_alt(nodes_v, c.j + 1);
+    while (__any(z >= c.above)) {
+        if (z >= c.above) {
+            ++c.j;
+            c.above = lds_alt(nodes_v, c.j + 1);
+        }
+    }
+    return c;
+}
+
 template <int MODE, bool CHECK, int POLY, bool HINT>
 __device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX,
                                             double hcY2, double acc, double wc, unsigned long long& viol,
-                                            unsigned nodes_v, unsigned hint_v) {
+                                            unsigned nodes_v, SegCursor& cur) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
-    // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
-    // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here.  (A float
-    // "magic number" add cannot replace the conversion: it rounds to nearest, and the interpolants are
-    // anchored at the level BELOW the point; the bias of -1/2 that would fix that is not representable
-    // next to 2^52.)
-    int j = (int)(m0 * kj);
     typedef __attribute__((address_space(3))) const char* LdsBytes;
     typedef __attribute__((address_space(3))) const double* LdsDouble;
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const vec2* LdsVec2;
+    int j;
     if (HINT) {
-        // j is a bucket (< kHintBuckets: m <= 1 and kj < kHintBuckets, checked by the caller)
-        typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
-        j = *(LdsU16)(uintptr_t)(hint_v + 2u * (unsigned)j);
         const double z = __builtin_fma(m0, span, a0);
-        // np.interp's segment: alt[j] <= z < alt[j+1]; level K is a +inf sentinel, so the walk stops by itself
-        double above = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)(j + 1), (unsigned)sizeof(Node)));
-        while (__any(z >= above)) {
-            if (z >= above) {
-                ++j;
-                above = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)(j + 1), (unsigned)sizeof(Node)));
+        // np.interp's segment: alt[j] <= z < alt[j+1]; alt[cur.j] <= z holds from this lane's previous point
+        while (__any(z >= cur.above)) {
+            if (z >= cur.above) {
+                ++cur.j;
+                cur.above = lds_alt(nodes_v, cur.j + 1);
             }
         }
+        j = cur.j;
+    } else {
+        // the pair table holds m clamped to [0, 1] (NaN -> 0), and kj = span / step <= K - 1 with
+        // span <= alt[K-1] - alt[0]: (int)(m * kj) is inside [0, K-1] without a clamp here.  (A float
+        // "magic number" add cannot replace the conversion: it rounds to nearest, and the interpolants are
+        // anchored at the level BELOW the point; the bias of -1/2 that would fix that is not representable
+        // next to 2^52.)
+        j = (int)(m0 * kj);
     }
     const LdsBytes pn = (LdsBytes)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
     double off = *(LdsDouble)(pn + 8);
     const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48);
     vec2 r_ub;
     if (POLY == 1) { r_ub.x = 0.0; r_ub.y = 0.0; }
-    else if (POLY == 2) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
+    else if (POLY == 2 || POLY == 4) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
     else r_ub = *(LdsVec2)(pn + 64);
     double2 dd = make_double2(r_dd.x, r_dd.y);                     // den, sden
     double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
@@ -784,11 +857,20 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
     // starts at a zero density it gives a density of -1e-8 x slope, i.e. X ~ -1e-9 at one point; this path
     // has no mu > 1 cliff test such a value could trip (the generic path, which has one, clamps), and the
     // effect on mu' there is of the same size - far below the reference's own noise.
-    if (HINT) x = fmax(x, 0.0);                                 // the table walk guarantees alt[j] <= z: rounding only
+    if (HINT) x = fmax(x, 0.0);                                 // the cursor guarantees alt[j] <= z: rounding only
     const double den = dd.y * x + dd.x;
     const double b = bb.y * x + bb.x;
-    const double C2 = POLY == 1 ? ua.x + x * ua.y
-                    : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
+    double C2;
+    if (POLY == 4) {
+        // rotation form: 2 cos^2(psi_j + r x) = 1 + cos 2psi_j cos t - sin 2psi_j sin t, t = 2 r x, |t| <= 2 kTrigAngle
+        const double t = ua.y * x, t2 = t * t;
+        const double ct = 1.0 + t2 * (-0.5 + t2 * (1.0 / 24.0 + t2 * (-1.0 / 720.0 + t2 * (1.0 / 40320.0))));
+        const double st = t * (1.0 + t2 * (-1.0 / 6.0 + t2 * (1.0 / 120.0 + t2 * (-1.0 / 5040.0 + t2 * (1.0 / 362880.0)))));
+        C2 = __builtin_fma(-ub.x, st, __builtin_fma(ua.x, ct, 1.0));
+    } else {
+        C2 = POLY == 1 ? ua.x + x * ua.y
+                       : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
+    }
     double a;
     const double mup = group_index_lean<MODE>(den, hcY2 * (b * b), C2, cX, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
@@ -898,13 +980,24 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     TopSegment top;
     __builtin_memset(&top, 0, sizeof top);
     bool top_phase = false;
-    if (TOP && !HINT && end - first >= PRHF_TOP_MIN_POINTS) {
+    if (TOP && end - first >= PRHF_TOP_MIN_POINTS) {
         const int i_last = (last_special >= 0 ? last_special : end - 1);
         const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, i_last * (int)sizeof(double2), 0);
         double2 gl;
         __builtin_memcpy(&gl, &vl, sizeof gl);
-        const int j_top = uniform((int)(gl.x * kj));
-        const double m_star = uniform((double)j_top / kj);
+        // the segment of the last point and the grid position m_star of its left end: closed form on a uniform altitude
+        // grid; through the hint table and the node's own offset (alt_0 - alt_j) otherwise
+        int j_top;
+        double m_star;
+        if (HINT) {
+            j_top = uniform(cursor_at(gl.x, span, a0v, kj, nodes_v, hint_v).j);
+            typedef __attribute__((address_space(3))) const double* LdsDouble;
+            const double off_top = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j_top, (unsigned)sizeof(Node)) + 8u);
+            m_star = uniform(-off_top / span);
+        } else {
+            j_top = uniform((int)(gl.x * kj));
+            m_star = uniform((double)j_top / kj);
+        }
         int lo = first, hi = i_last + 1;               // the answer lies in [lo, hi): m[hi - 1] >= m_star
         bool found = uniform((int)(gl.x >= m_star)) != 0;
         while (found && hi - lo > 1) {
@@ -932,18 +1025,22 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     double accm = 0.0;                                 // sum of mu' * weight
     unsigned long long viol = 0;
     double2 g0 = grid_at(first);
+    SegCursor cur;
+    cur.j = 0;
+    cur.above = 0.0;
+    if (HINT) cur = cursor_at(first + lane < end ? g0.x : uniform(g0.x), span, a0v, kj, nodes_v, hint_v);
     // two wave-iterations per trip so that the prefetch registers swap roles without moves
     for (; first + 128 <= split; first += 128) {
         const double2 g1 = grid_at(first + 64);
         if (!CHECK) {
-            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
             g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
         } else {
             unsigned long long viol2 = 0;
-            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
             const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, hint_v);
+            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, cur);
             if (viol) {                                // keep the points in front of the first one that fails
                 const int L = __ffsll((long long)viol) - 1;
                 if (lane < L) accm = a1;
@@ -962,7 +1059,7 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
         }
     }
     if (!(CHECK && viol) && first + 64 <= split) {     // odd whole wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
+        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
         if (!(CHECK && viol)) {
             accm = a1;
             first += 64;
@@ -1027,8 +1124,10 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
             if (!live) g = make_double2(uniform(g0.x), 0.0);
             a1 = lean_step_top<MODE, CHECK, POLY>(g, top, cX, hcY2, accm, wc, viol);
         } else {
-            if (!live) g = make_double2(0.0, 0.0);     // an idle lane re-evaluates grid point 0 with weight 0
-            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, hint_v);
+            // an idle lane re-evaluates a live point with weight 0: grid point 0 - or, under the cursor (whose lanes may
+            // only move up), this iteration's first point, which lies above everything the lane has seen
+            if (!live) g = make_double2(HINT ? uniform(g0.x) : 0.0, 0.0);
+            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
         }
         if (!(CHECK && viol)) {
             accm = a1;
@@ -1042,56 +1141,6 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     }
     LeanResult r;
     r.acc = accm * span;                               // :415: dh = (m_i+1 - m_i) * span
-    r.first = first;
-    return r;
-}
-
-// The checked main loop for the short grids of run_items_tail16: grid points [0, end) of one pair, end <= 1000,
-// inlined into the item loop.  On a 200-point grid a pair has three wave-iterations of points, and the call of
-// lean_loop - arguments through vector registers and back into scalars, the dynamic-LDS base from its table, the
-// two-iterations-per-trip control flow - was a quarter of what the pair cost.  One wave-iteration per trip, the next
-// trip's grid entries loaded in front; every argument is wave-uniform already.  Same arithmetic, same stop rule
-// (in front of the first point with 1 - X <= wc) as lean_loop<MODE, true, POLY, HINT, false>.
-template <int MODE, int POLY, bool HINT>
-__device__ __forceinline__ LeanResult lean_checked_short(unsigned nodes_lds, unsigned hint_lds,
-                                                         const double2* __restrict__ pairs, int end, double span,
-                                                         double a0, double kj, double cX, double cY2, double wc) {
-#pragma clang fp contract(fast)
-    const int lane = threadIdx.x & 63;
-    const double hcY2 = uniform(0.5 * cY2);
-    double a0v = a0;
-    unsigned nodes_v = nodes_lds, hint_v = hint_lds;
-    asm volatile("" : "+v"(a0v), "+v"(nodes_v), "+v"(hint_v));
-    const unsigned voff = (unsigned)lane * (unsigned)sizeof(double2);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double2*>(pairs), 0, 0x7fffffff, 0x00020000);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    auto grid_at = [&](int i) {                    // entries past `end` are read (the table is padded) and not used
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, i * (int)sizeof(double2), 0);
-        double2 g;
-        __builtin_memcpy(&g, &v, sizeof g);
-        return g;
-    };
-    double acc = 0.0;
-    unsigned long long viol = 0;
-    int first = 0;
-    double2 g = grid_at(0);
-    while (first < end) {
-        const double2 gn = grid_at(first + 64);
-        if (first + lane >= end) g = make_double2(0.0, 0.0);       // an idle lane re-evaluates grid point 0 with weight 0
-        const double a1 = lean_step<MODE, true, POLY, HINT>(g, span, a0v, kj, cX, hcY2, acc, wc, viol, nodes_v, hint_v);
-        if (viol) {
-            const int L = __ffsll((long long)viol) - 1;
-            if (lane < L) acc = a1;
-            first += L;
-            break;
-        }
-        acc = a1;
-        first = min(first + 64, end);
-        g = gn;
-    }
-    LeanResult r;
-    r.acc = acc * span;
     r.first = first;
     return r;
 }
@@ -1119,11 +1168,12 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
     const int K = info.K;
     const double a0 = info.a0;
     const double span = uniform(h_refl - a0);      // :413 (critical_height - aalt[0])
-    const bool poly_angle = info.poly_angle != 0;
+    const bool poly_angle = info.poly_angle != 0 && info.poly_angle != 4;      // every segment on a polynomial
+    const bool lean_angle = info.poly_angle != 0;                              // ... or in rotation form: main loop
     const int last = n_points - 1;
     double acc = 0.0;
     int first = i0;                                // first grid point of the next wave-iteration
-    if (!UNMAG && poly_angle && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
+    if (!UNMAG && lean_angle && pairs != nullptr && (TIER == 1 || well_conditioned < 1.0)) {
         // Lean main loop of the common case (slowly turning field; uniform altitude grid, or any grid
         // through the hint table).  Fast tier: it takes every grid point of the range, the last one of the
         // grid (thickness 1e-6 km) included, so nothing is left for the generic loop below.  Default O-mode
@@ -1149,12 +1199,16 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
             const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
             const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
-            const int poly = 4 - info.poly_angle;           // degree: 3 cubic, 2 quadratic, 1 linear
+            const int poly = info.poly_angle == 4 ? 4 : 4 - info.poly_angle;    // degree: 3 cubic, 2 quadratic, 1 linear; 4: rotation form
             LeanResult r;
 #define PRHF_LEAN(P, H, T) lean_loop<MODE, TIER == 0, P, H, T>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
                                                                  span, a0, kj, cX, cY2, well_conditioned)
 #define PRHF_LEAN_POLY(H, T) (poly == 1 ? PRHF_LEAN(1, H, T) : (poly == 2 ? PRHF_LEAN(2, H, T) : PRHF_LEAN(3, H, T)))
-            if (by_hint) r = PRHF_LEAN_POLY(true, false);
+            if (poly == 4) r = by_hint ? PRHF_LEAN(4, true, false) : PRHF_LEAN(4, false, false);
+            else if (by_hint) {
+                if (lean_end - first >= PRHF_TOP_MIN_POINTS && i0 == 0 && to_grid_end) r = PRHF_LEAN_POLY(true, true);
+                else r = PRHF_LEAN_POLY(true, false);
+            }
             // (a chunk of a pair keeps to the indexed steps: the search for the top segment's first point costs
             // three dependent loads, which a latency-bound chunked launch cannot hide and every chunk would repeat)
             else if (lean_end - first >= PRHF_TOP_MIN_POINTS && i0 == 0 && to_grid_end) r = PRHF_LEAN_POLY(false, true);
@@ -1428,7 +1482,8 @@ __device__ __forceinline__ PairFreq pair_freq(const KArgs& a, int f) {
         p.f_hz = uniform(row[0]); p.f2 = uniform(row[1]); p.cX = uniform(row[2]); p.cY2 = uniform(row[3]);
         p.inv_f2 = uniform(row[4]); p.inv_f = uniform(row[5]);
     } else {
-        p.f_hz = uniform(a.freq[f] * 1e6);                     // :491
+        const double fm = a.freq[f];                           // (not positive and finite: NaN, see freq_table_kernel)
+        p.f_hz = uniform((fm > 0.0 && fm < __builtin_inf()) ? fm * 1e6 : qnan());     // :491
         p.f2 = uniform(p.f_hz * p.f_hz);                       // f**2
         p.cX = uniform((kPlasma * kPlasma) / p.f2);
         const double cY = kGyro / p.f_hz;
@@ -1470,7 +1525,7 @@ __device__ __forceinline__ bool pair_reflects(const Node* nodes, const double* p
 template <int MODE, int TIER>
 __device__ __forceinline__ double one_level_term(const Node* nodes, const BlockInfo& info, const PairFreq& pf,
                                                  double well_conditioned) {
-    const bool poly = info.poly_angle != 0;
+    const bool poly = info.poly_angle != 0 && info.poly_angle != 4;
     const double mup = info.unmag
         ? point_mup<MODE, TIER, true>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned)
         : point_mup<MODE, TIER, false>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned);
@@ -1498,7 +1553,7 @@ __device__ __forceinline__ bool collapsed_grid_sum(const Node* nodes, const Bloc
     const double z_last = mult[n_points - 1] * span + info.a0;
     const double S = (z_last - z_first) + kBackoff;
     if (!(__builtin_fabs(S) > 1e-21)) return false;
-    const bool poly = info.poly_angle != 0;
+    const bool poly = info.poly_angle != 0 && info.poly_angle != 4;
     const double mup = info.unmag
         ? point_mup<MODE, TIER, true>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned)
         : point_mup<MODE, TIER, false>(nodes[0], 0.0, pf.f_hz, pf.f2, pf.cX, pf.cY2, poly, well_conditioned);
@@ -1581,142 +1636,6 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
     }
 }
 
-// Short grids in the default O-mode arithmetic (BASELINE config 3: n_points = 200): an item is FOUR
-// consecutive frequencies.  What costs most there is not the 200 points but the one wave-iteration in the
-// reference's operation order (~500 vector instructions) that every reflecting pair needs for its
-// ill-conditioned last points - and those are few: with the threshold 1 - X <= 1e-5 they are the last 1 to 4
-// of 200 grid points (98 % of the pairs: the last 16 at most).  So each pair runs the main loop, with its
-// check, over everything but its last 16 points, and the four tails of 16 share ONE wave-iteration in the
-// reference's order: lane l evaluates point n - 16 + (l & 15) of pair l >> 4 with that pair's own
-// frequency and reflection height.  A pair whose check fails before its tail (an E-F cusp, a bottom that
-// starts above cutoff) goes through the general path by itself.  Values do not depend on which pairs
-// share an iteration: the tail is always evaluated in the reference's order, point by point.
-constexpr int kTail = 16;
-// (-DPRHF_TAIL_LEAN=lean_loop or =lean_loop_body: the general loop, called or inlined, instead of lean_checked_short - A/B)
-template <int MODE, int THREADS>
-__device__ __forceinline__ void run_items_tail16(const KArgs& a, const SegDev& sg, const Node* nodes,
-                                                 const double* pf2, const double* gb,
-                                                 const unsigned short* hint, const unsigned short* cand,
-                                                 const BlockInfo& info, long long prof_local, int block_in_prof,
-                                                 int blocks_per_prof, int* item_next, const double* red) {
-    constexpr int W = THREADS / 64;
-    constexpr int TIER = 0;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane >> 4;                     // which of the item's four pairs this lane's tail point belongs to
-    const double* keep = kept_scalars<THREADS>(red);
-    const double wc = uniform(sg.well_conditioned);
-    const int F = uniform((int)a.n_freq);
-    const int count = info.n_cand >= 0 ? info.n_cand : F;      // frequencies to evaluate (candidate list or all)
-    const int T = (count + 3) >> 2;
-    const int n = uniform(sg.n_points);
-    const double* mult = a.mult + sg.mult_off;
-    const double2* pairs = reinterpret_cast<const double2*>(a.pairs) + sg.mult_off;
-    const long long pair_base = prof_local * F;
-    const int first_item = block_in_prof * W, round_items = blocks_per_prof * W;
-    auto next_item = [&]() {
-        const int u = uniform(atomicAdd(item_next, 1)) >> 6;
-        return uniform((u / W) * round_items + first_item + (u % W));
-    };
-    const double a0 = info.a0;
-    const bool by_hint = !info.uniform;
-    typedef __attribute__((address_space(3))) const Node* LdsNodes;
-    typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
-    const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
-    const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
-    const int poly = 4 - info.poly_angle;              // degree of the angle polynomials: 3, 2 or 1
-    const double alt_min = keep[kKeepAltMin];
-    const int ti = n - kTail + (lane & 15);        // this lane's tail point
-    for (int t = next_item(); t < T; t = next_item()) {
-        const int e0 = t << 2;
-        // per-lane parameters of the pair whose tail point this lane evaluates; my_sum: what the four lanes
-        // l, l ^ 16, l ^ 32, l ^ 48 accumulated in that pair's main loop (the tail's reduction below finishes the sum)
-        double my_fhz = 1.0, my_f2 = 1.0, my_h = 0.0, my_sum = 0.0;
-        int my_f = -1;
-        unsigned tail_mask = 0;                    // bit q: pair q takes part in the shared tail iteration
-        double my_done = qnan();                   // result of this lane's pair if it does not (NaN: escapes)
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            if (e0 + q >= count) continue;
-            const int f = info.n_cand >= 0 ? uniform((int)cand[e0 + q]) : e0 + q;
-            if (sub == q) my_f = f;
-            const PairFreq pf = pair_freq(a, f);
-            double h = 0.0;
-            if (!pair_reflects<MODE>(nodes, pf2, gb, info, keep, pf, lane, e0 + q, &h)) continue;   // (K > 1 on this path)
-            const double span = uniform(h - a0);
-            const double kj = uniform(by_hint ? span * info.inv_w * (1.0 - 1e-11) : span * info.inv_step);
-            const bool in_table = by_hint ? (kj < (double)kHintBuckets && info.inv_w > 0.0)
-                                          : (kj <= (double)(info.K - 1));
-            bool shared = false;
-            if (span > 0.0 && in_table) {
-                LeanResult r;
-#ifdef PRHF_TAIL_LEAN
-#define PRHF_LEAN(P, H) PRHF_TAIL_LEAN<MODE, true, P, H, false>(nodes_lds, hint_lds, pairs, 0, n - kTail, -1, span, a0, kj, \
-                                                             pf.cX, pf.cY2, wc)
-#else
-#define PRHF_LEAN(P, H) lean_checked_short<MODE, P, H>(nodes_lds, hint_lds, pairs, n - kTail, span, a0, kj, pf.cX, pf.cY2, wc)
-#endif
-                if (by_hint) r = poly == 1 ? PRHF_LEAN(1, true) : (poly == 2 ? PRHF_LEAN(2, true) : PRHF_LEAN(3, true));
-                else r = poly == 1 ? PRHF_LEAN(1, false) : (poly == 2 ? PRHF_LEAN(2, false) : PRHF_LEAN(3, false));
-#undef PRHF_LEAN
-                if (uniform(r.first) == n - kTail &&
-                    !uniform((int)__any(!(__builtin_fabs(r.acc) <= 1.7976931348623157e308)))) {
-                    shared = true;
-                    tail_mask |= 1u << q;
-                    double s0, s1;
-                    halves(r.acc, &s0, &s1);
-                    double s = s0 + s1;
-                    s = s + lane_xor<16>(s);
-                    if (sub == q) { my_fhz = pf.f_hz; my_f2 = pf.f2; my_h = h; my_sum = s; }
-                }
-            }
-            if (!shared) {                         // the general path, this pair by itself
-                double total = 0.0;
-                // (a frequency below the plasma frequency of the bottom level: the grid collapses onto that level)
-                if (!(h < a0 && uniform((int)collapsed_grid_sum<MODE, TIER>(nodes, info, pf, mult, n, h, sg.well_conditioned,
-                                                                            &total))))
-                    total = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, n, 0, n, pf.f_hz, pf.f2,
-                                                               pf.cX, pf.cY2, h, lane, wc);
-                if (sub == q) my_done = (total != 0.0) ? total + alt_min : qnan();            // :290-292
-            }
-        }
-        double shared_vh = qnan();
-        if (tail_mask) {
-            // one wave-iteration in the reference's operation order for up to four tails of 16 points
-#pragma clang fp contract(off)
-            const bool live = (tail_mask >> sub) & 1u;
-            const double tm0 = mult[ti];                                         // (not kept across the loop calls above)
-            const double tm1 = mult[ti + 1 < n ? ti + 1 : ti];
-            const double span = my_h - a0;                                       // :413
-            const double z = tm0 * span + a0;
-            const double dh = (ti < n - 1) ? (tm1 * span + a0) - z : kBackoff;   // :415-416
-            int j = guess_segment(hint, info, z);
-            while (j > 0 && z < nodes[j].alt) --j;                               // np.interp: alt[j] <= z < alt[j+1]
-            while (j + 1 < info.K && z >= nodes[j + 1].alt) ++j;
-            const Node nd = nodes[j];
-            double dz = z - nd.alt;
-            if (dz < 0.0) dz = 0.0;
-            const double den = nd.sden * dz + nd.den;                            // numpy arr_interp
-            const double fn = sqrt(den) * kPlasma;                               // :96
-            const double X = (fn * fn) / my_f2;                                  // :136
-            const double b = nd.sb * dz + nd.b;
-            const double psi = nd.spsi * dz + nd.psi;
-            const double Y = (kGyro * b) / my_fhz;                               // :157
-            double mu, mup;
-            index_faithful<MODE>(X, Y, psi, &mu, &mup);
-            double term = mup * dh;                                              // :288
-            if (!(live && term == term)) term = 0.0;                             // nansum
-            // sum over the 16 lanes of each pair: its tail terms and its main loop's four-lane partial sums
-            double total = term + my_sum;
-            total = total + lane_xor<8>(total); total = total + lane_xor<4>(total);
-            total = total + lane_xor<2>(total); total = total + lane_xor<1>(total);
-            shared_vh = (total != 0.0) ? total + alt_min : qnan();               // :290-292
-        }
-        // lanes 0, 16, 32, 48 store their pair's result
-        if ((lane & 15) == 0 && my_f >= 0)
-            a.out[sg.out_off + pair_base + my_f] = ((tail_mask >> sub) & 1u) ? shared_vh : my_done;
-    }
-}
-
 }  // namespace
 
 // Returns the wall clock at the end of staging in -DPRHF_TRACE builds (0 otherwise).
@@ -1753,18 +1672,10 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     const unsigned long long t_staged = 0;
 #endif
     if (threadIdx.x == 0 && block_in_prof == 0) {
-        if (info.bad) atomicOr(a.status, (unsigned)info.bad);
+        if (info.bad) post_status(a.status, (unsigned)info.bad);
         if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
     }
-    if (TIER == 0 && sg.group == 4 && !info.bad && !info.unmag && info.poly_angle != 0 && info.K > 1) {
-        // short grids, default O-mode arithmetic: four frequencies per item (run_items_tail16)
-        if (sg.mode == PRHF_KMODE_O)
-            run_items_tail16<PRHF_KMODE_O, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
-                                                    blocks_per_prof, item_next, red);
-        else
-            run_items_tail16<PRHF_KMODE_X, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
-                                                    blocks_per_prof, item_next, red);
-    } else if (sg.mode == PRHF_KMODE_O)
+    if (sg.mode == PRHF_KMODE_O)
         run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     else
@@ -1900,7 +1811,10 @@ __global__ void freq_table_kernel(const double* __restrict__ freq_mhz, long long
 #pragma clang fp contract(off)
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_freq) return;
-    const double f_hz = freq_mhz[f] * 1e6;                     // :491
+    // A frequency that is not a positive finite number is carried as NaN: every comparison of the level search then
+    // fails and the column comes out NaN (the reference: NaN for 0 and NaN, something meaningless for f < 0).
+    const double fm = freq_mhz[f];
+    const double f_hz = (fm > 0.0 && fm < __builtin_inf()) ? fm * 1e6 : qnan();       // :491
     const double f2 = f_hz * f_hz;                             // f**2
     const double cY = kGyro / f_hz;
     double* row = tab + 8 * f;
@@ -2181,7 +2095,7 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
     const double one_mhz = 1.0;     // stage_profile only needs a frequency column for the isotropic test
     const BlockInfo info = stage_profile<0, THREADS>(a.den, a.bmag, a.bpsi, a.alt, &one_mhz, 0, n_alt, nodes,
                                                      pf2, gb, hint, red);
-    if (threadIdx.x == 0 && info.bad) atomicOr(a.status, (unsigned)info.bad);
+    if (threadIdx.x == 0 && info.bad) post_status(a.status, (unsigned)info.bad);
     if (a.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     const double f_hz = a.freq_hz[f];
     double h = qnan();

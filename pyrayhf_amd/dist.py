@@ -30,17 +30,18 @@ def shard_counts(n_items, world_size):
             for r in range(world_size)]
 
 
-def gather_rows(local, n_total, group=None):
+def gather_rows(local, n_total, group=None, force=False):
     """All-gather row shards (unequal row counts allowed) into ``(n_total, F)`` on every rank.
 
     ``local`` is this rank's ``(P_r, F)`` tensor, where ``P_r`` follows ``shard_bounds``.
     Equal shards go through one ``all_gather_into_tensor``; ragged ones are padded to the
-    largest shard first.
+    largest shard first.  A group of one rank returns ``local`` itself unless ``force`` is set:
+    then the rows go through the collective anyway (the N > 1 code path on one GPU).
     """
     import torch
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     counts = shard_counts(n_total, world)
@@ -89,11 +90,12 @@ def shard_segments(segments, world_size, rank):
     return (np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)), local
 
 
-def gather_mixed(local, segments, n_total, group=None):
+def gather_mixed(local, segments, n_total, group=None, force=False):
     """Reassemble the ``(n_total, F)`` result of a mixed work list cut by ``shard_segments``.
 
     ``local`` holds this rank's rows in ``shard_segments`` order.  One padded all-gather, then each
-    rank's rows go back to their global positions; rows no segment covers stay NaN.
+    rank's rows go back to their global positions; rows no segment covers stay NaN.  ``force``: a
+    group of one rank goes through the collective too (see ``gather_rows``).
     """
     import numpy as np
     import torch
@@ -105,7 +107,7 @@ def gather_mixed(local, segments, n_total, group=None):
     if local.shape[0] != cuts[rank].size:
         raise ValueError("local rows do not match shard_segments for this rank")
     full = torch.full((int(n_total), local.shape[1]), float("nan"), dtype=local.dtype, device=local.device)
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         full[torch.as_tensor(cuts[0], device=local.device)] = local
         return full
     biggest = max(max(c.size for c in cuts), 1)

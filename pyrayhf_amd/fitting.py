@@ -20,9 +20,9 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from .library import _mode_code, _multiplier, _as_rows, MATH_AUTO
+from .library import _mode_code, _multiplier, _as_rows, _is_torch, _device_grid, MATH_AUTO
 
-__all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace"]
+__all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace", "brute_grid", "minimize_parameters"]
 
 
 def _sorted_finite(freq, vh_obs):
@@ -45,8 +45,13 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
     (km) are used as given (no filtering or sorting).  Returns ``(residual (P, F), cost (P,))`` with
     ``cost = sum(residual**2, axis=1)``, or only ``residual`` when ``return_cost`` is false; with
     ``return_vh`` the modeled traces ``(P, F)`` (NaN where a frequency escapes) are appended.
+
+    A GPU-resident torch ``den`` (the other arguments tensors on the same device, or array-likes that are
+    uploaded) is used in place and gives tensors on that device: candidates built on the GPU never visit the host.
     """
     code = _mode_code(mode)
+    if _is_torch(den) and den.is_cuda:
+        return _torch_residual(freq, vh_obs, den, bmag, bpsi, alt, code, n_points, math, return_cost, return_vh)
     f = np.ascontiguousarray(np.atleast_1d(freq), dtype=np.float64)
     obs = np.ascontiguousarray(np.atleast_1d(vh_obs), dtype=np.float64)
     if f.shape != obs.shape or f.ndim != 1:
@@ -77,6 +82,50 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
                                        obs.ctypes.data, vh.ctypes.data if return_vh else None,
                                        residual.ctypes.data, cost.ctypes.data,
                                        _native.FLAG_SHARED_FIELD if shared else 0))
+    out = (residual, cost) if return_cost else (residual,)
+    if return_vh:
+        out = out + (vh,)
+    return out if len(out) > 1 else out[0]
+
+
+def _torch_residual(freq, vh_obs, den, bmag, bpsi, alt, code, n_points, math, return_cost, return_vh):
+    import torch
+
+    dev = den.device
+
+    def prep(x, name):
+        if not _is_torch(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev)
+        if x.device != dev:
+            raise ValueError(f"{name} is on {x.device}, expected {dev}")
+        return x.to(torch.float64).contiguous()
+
+    f, obs = prep(freq, "freq").reshape(-1), prep(vh_obs, "vh_obs").reshape(-1)
+    if f.shape != obs.shape:
+        raise ValueError("freq and vh_obs must be 1-D arrays of one length")
+    d2 = prep(den, "den")
+    d2 = d2.reshape(1, -1) if d2.dim() == 1 else d2
+    n_prof, n_alt = d2.shape
+    b2, p2, a = prep(bmag, "bmag"), prep(bpsi, "bpsi"), prep(alt, "alt")
+    shared = b2.dim() == 1 and p2.dim() == 1
+    if shared:
+        if b2.shape != (n_alt,) or p2.shape != (n_alt,):
+            raise ValueError("bmag and bpsi must have one value per density level")
+    elif b2.shape != d2.shape or p2.shape != d2.shape:
+        raise ValueError("bmag and bpsi must be (N_alt,) or have den's shape")
+    if a.shape != (n_alt,):
+        raise ValueError("alt must be 1-D with one value per density level")
+    mult, grid_flag = _device_grid((int(n_points),), dev)
+    residual = torch.empty((n_prof, f.numel()), dtype=torch.float64, device=dev)
+    cost = torch.empty(n_prof, dtype=torch.float64, device=dev)
+    vh = torch.empty((n_prof, f.numel()), dtype=torch.float64, device=dev) if return_vh else None
+    ctx = _native.context(dev.index if dev.index is not None else torch.cuda.current_device())
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.set_math(MATH_AUTO if math is None else int(math))
+    _native.raise_for(ctx.vfo_residual(f.data_ptr(), f.numel(), d2.data_ptr(), b2.data_ptr(), p2.data_ptr(), a.data_ptr(),
+                                       n_prof, n_alt, n_alt, 0, mult.data_ptr(), int(n_points), code, obs.data_ptr(),
+                                       vh.data_ptr() if return_vh else None, residual.data_ptr(), cost.data_ptr(),
+                                       _native.FLAG_DEVICE_PTRS | grid_flag | (_native.FLAG_SHARED_FIELD if shared else 0)))
     out = (residual, cost) if return_cost else (residual,)
     if return_vh:
         out = out + (vh,)
@@ -120,3 +169,86 @@ def peak_density_from_trace(f_max_mhz, mode='O', *, alt=None, bmag=None, hmf2=No
         f_c = np.asarray(bmag, dtype=np.float64)[int(np.argmin(np.abs(np.asarray(alt, dtype=np.float64) - hmf2)))] * g_p
         return freq2den(np.sqrt(f_max_hz ** 2 - f_max_hz * f_c)) * 1.0001     # from X + Y = 1
     raise ValueError("mode must be 'O' or 'X'")
+
+
+def brute_grid(value, percent_sigma=20.0, step=1.0):
+    """The nodes lmfit's brute-force search walks for one parameter of ``minimize_parameters``.
+
+    The reference gives the parameter ``min = value - sigma``, ``max = value + sigma`` with
+    ``sigma = value * percent_sigma / 100`` and ``brute_step = step`` (library.py:746-757, :783-792).  lmfit
+    turns a parameter with a ``brute_step`` into ``slice(min, max, brute_step)`` and hands the slices to
+    ``scipy.optimize.brute``, which expands them with ``np.mgrid`` - i.e. ``np.arange(min, max, step)``: the first
+    node is ``min`` and ``max`` itself is excluded.  lmfit is not installed in the build container (and not
+    vendored by the reference, pyproject.toml:41), so this end-point convention is taken from its documentation:
+    **parity unpinned** for the node set itself; everything evaluated AT the nodes is pinned (fixture G11).
+    """
+    value = float(np.asarray(value).squeeze())
+    sigma = value * (float(percent_sigma) / 100.0)
+    return np.arange(value - sigma, value + sigma, float(step))
+
+
+def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='brute', percent_sigma=20., step=1.,
+                        mode='O', n_points=200, bottom_type='B_bot', *, edp_builder, device=None, math=None):
+    """Fit hmF2 and B_bot (or B0) of the F2 layer to an observed trace: the reference's ``minimize_parameters``
+    (library.py:672-825) with its brute-force search as ONE batched launch.
+
+    Positional arguments, defaults and the returned triple ``(vh_result, EDP_result, F2_fit)`` are the
+    reference's.  What the reference gets from PyIRI inside ``model_VH`` (library.py:557-586) comes from the
+    caller here, because PyIRI is not vendored: ``edp_builder(F2, F1, E, alt, bottom_type)`` must return the
+    electron density profile ``(N_alt,)`` [m^-3] for the layer dictionaries it is given - with PyIRI installed,
+    a wrapper around ``reconstruct_density_from_parameters_1level`` / ``EDP_builder_continuous``.
+
+    As in the reference: observations are filtered to finite values and sorted (:741-745); NmF2 is fixed from
+    the highest observed frequency (+0.01 %, :760-778); hmF2 and B_bot (``bottom_type='B_bot'``) or B0
+    (``'B0_B1'``) scan ``brute_grid`` around their initial values; every node's residual is ``residual_VH``
+    (:636-669: layer parameters written with ``np.full_like(F2['Nm'], ...)``, modeled NaNs replaced by
+    ``max(nanmean|vh|, 100)``); the node with the smallest sum of squares wins (the first one on a tie:
+    ``scipy.optimize.brute`` takes ``argmin`` of the grid, first parameter outermost); the final trace is
+    evaluated at the UNfiltered input frequencies (:821-824).  Only ``method='brute'`` exists here - the
+    reference's other methods are lmfit's own optimisers.
+    """
+    from copy import deepcopy
+
+    if (bottom_type == 'B_bot') and (F2.get('B_bot') is None):
+        raise ValueError('B_bot is not provided in F, but bottom_type is B_bot')                   # :730-732
+    if (bottom_type == 'B0_B1') and ((F2.get('B0') is None) or (F2.get('B1') is None)):
+        raise ValueError('B0 and B1 are not provided in F, but bottom_type is B0_B1')              # :734-736
+    if bottom_type not in ('B_bot', 'B0_B1'):
+        raise ValueError("bottom_type must be 'B_bot' or 'B0_B1'")
+    if method != 'brute':
+        raise NotImplementedError("only method='brute' is batched here; the reference's other methods are lmfit's")
+    f_in0 = np.asarray(f_in0, dtype=np.float64)
+    vh_obs0 = np.asarray(vh_obs0, dtype=np.float64)
+    alt = np.asarray(alt, dtype=np.float64)
+    f_in, vh_obs = _sorted_finite(f_in0, vh_obs0)
+    if f_in.size == 0:
+        raise ValueError("no finite observation")
+    old_hmf2 = float(np.asarray(F2['hm']).squeeze())
+    second = 'B_bot' if bottom_type == 'B_bot' else 'B0'
+    nmf2_new = peak_density_from_trace(f_in[-1], mode, alt=alt, bmag=b_mag, hmf2=old_hmf2)
+    hm_nodes = brute_grid(F2['hm'], percent_sigma, step)
+    bb_nodes = brute_grid(F2[second], percent_sigma, step)
+    if hm_nodes.size == 0 or bb_nodes.size == 0:
+        raise ValueError("empty search grid: percent_sigma too small for this step")
+
+    def layers(hm, bb):
+        f2 = deepcopy(F2)
+        f2['Nm'] = np.full_like(F2['Nm'], nmf2_new)
+        f2['hm'] = np.full_like(F2['Nm'], hm)
+        f2[second] = np.full_like(F2['Nm'], bb)
+        return f2
+
+    nodes = [(hm, bb) for hm in hm_nodes for bb in bb_nodes]
+    den = np.empty((len(nodes), alt.size), dtype=np.float64)
+    for k, (hm, bb) in enumerate(nodes):
+        den[k] = np.asarray(edp_builder(layers(hm, bb), deepcopy(F1), deepcopy(E), alt, bottom_type), dtype=np.float64).ravel()
+    _, cost = residual_VH_batch(f_in, vh_obs, den, b_mag, b_psi, alt, mode, n_points, device=device, math=math)
+    finite = np.isfinite(cost)
+    if not finite.any():
+        raise ValueError("no node of the search grid produced a finite cost")
+    best = int(np.argmin(np.where(finite, cost, np.inf)))
+    F2_fit = layers(*nodes[best])
+    EDP_result = np.asarray(edp_builder(deepcopy(F2_fit), deepcopy(F1), deepcopy(E), alt, bottom_type), dtype=np.float64).ravel()
+    from .library import vertical_forward_operator
+    vh_result = vertical_forward_operator(f_in0, EDP_result, b_mag, b_psi, alt, mode, n_points, device=device, math=math)
+    return vh_result, EDP_result, F2_fit

@@ -29,7 +29,7 @@ __all__ = [
 
 MATH_FAITHFUL = _native.MATH_FAITHFUL   # reference operation order, IEEE divide / sqrt
 MATH_FAST = _native.MATH_FAST           # reduced algebra, rsqrt + Newton, FMA contraction
-MATH_AUTO = _native.MATH_AUTO           # default, per slice: 'X' fast; 'O' reference order where 1 - X <= 1e-4, fast elsewhere
+MATH_AUTO = _native.MATH_AUTO           # default, per slice: 'X' fast; 'O' reference order where 1 - X <= 1e-5, fast elsewhere
 
 
 # ----------------------------------------------------------------------------------------
@@ -188,22 +188,28 @@ def _is_torch(x):
 
 
 def _as_rows(name, x):
-    a = np.ascontiguousarray(np.asarray(x), dtype=np.float64)
+    if type(x) is np.ndarray and x.dtype == np.float64 and x.flags.c_contiguous:
+        a = x                                        # the usual call: nothing to convert
+    else:
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.float64)
     if a.ndim == 0 or a.ndim > 2:
         raise ValueError(f"{name} must be 1-D (one profile) or 2-D (profiles x levels)")
     return a
 
 
 def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
-    f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
+    if type(freq) is np.ndarray and freq.ndim == 1 and freq.dtype == np.float64 and freq.flags.c_contiguous:
+        f = freq
+    else:
+        f = np.ascontiguousarray(np.atleast_1d(np.asarray(freq)), dtype=np.float64)
     if f.ndim != 1:
         raise ValueError("freq must be a scalar or 1-D")
-    d, b, p, a = (_as_rows(n, x) for n, x in (("den", den), ("bmag", bmag), ("bpsi", bpsi), ("alt", alt)))
+    d, b, p, a = _as_rows("den", den), _as_rows("bmag", bmag), _as_rows("bpsi", bpsi), _as_rows("alt", alt)
     single = d.ndim == 1
     # batch extension: one bmag / bpsi row may serve every density row (an ensemble or a fit at one site)
     shared = d.ndim == 2 and b.ndim == 1 and p.ndim == 1 and b.shape == p.shape == d.shape[1:]
-    d2 = np.atleast_2d(d)
-    b2, p2 = (b, p) if shared else (np.atleast_2d(b), np.atleast_2d(p))
+    d2 = d.reshape(1, -1) if single else d
+    b2, p2 = (b, p) if shared else (b.reshape(1, -1) if b.ndim == 1 else b, p.reshape(1, -1) if p.ndim == 1 else p)
     if not shared and not (d2.shape == b2.shape == p2.shape):
         logger.error("Error: freq, den, bmag, bpsi, alt should have same size")   # reference library.py:487-488
         raise ValueError("den, bmag and bpsi must have the same shape")
@@ -300,7 +306,7 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     Keyword-only extensions: ``device`` (GPU index for host inputs; default ``PRHF_DEVICE``
     / ``LOCAL_RANK`` / 0), ``math`` (``MATH_FAITHFUL``: the reference's operation order at every
     grid point; ``MATH_FAST``: the reduced algebra at every point; default ``MATH_AUTO``: fast for
-    'X'; for 'O' the reference's order where 1 - X <= 1e-4 - where it decides the answer - and the
+    'X'; for 'O' the reference's order where 1 - X <= 1e-5 - where it decides the answer - and the
     reduced algebra elsewhere, which reproduces the reference to 1e-10),
     and for GPU-resident torch inputs ``sync`` (wait and surface data errors) and ``out``.
     With 2-D ``den``, 1-D ``bmag`` and ``bpsi`` are one field row shared by every profile.
@@ -309,6 +315,14 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     non-negative")`` (reference library.py:395-396, :93-94), ``IndexError`` when the density
     peak is the first level (the reference fails with IndexError there too), and
     ``ValueError`` on shape mismatch (the reference only logs, library.py:487-488).
+
+    Where this differs from the reference, on purpose: a profile may have at most 1400 levels (its
+    bottomside is held in the GPU's local memory; the reference has no limit) - ``ValueError``
+    beyond; a NaN in ``den`` or ``alt``, or in ``bmag`` / ``bpsi`` below the density peak, raises
+    ``ValueError`` (the reference lets ``np.argmax`` / ``np.interp`` spread it over the profile's
+    whole trace); a frequency that is not a positive finite number gives NaN for that frequency
+    and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for a
+    negative frequency).
     """
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):
@@ -395,6 +409,13 @@ def _torch_mixed(freq, den, bmag, bpsi, alt, segments, math, sync=True):
     if sync or not grid_flag:
         _native.raise_for(ctx.sync())          # an uncached `mult` must stay alive until the kernel has read it
     return out
+
+
+def set_option(name, value, device=None):
+    """A launch-shaping or arithmetic setting of this thread's context on ``device`` (``prhf_ctx_set_option``
+    in include/prhf.h: tests and A/B measurements; the defaults are the measured best).  The library reads
+    no environment variable."""
+    _native.context(device).set_option(name, value)
 
 
 def last_kernel_ms(device=None):

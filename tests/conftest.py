@@ -15,6 +15,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def apply_test_options():
+    """PRHF_TEST_OPTIONS="name=value,..." (set by the tests that re-run a subset under other launch settings):
+    applied through the library's explicit option call - the library itself reads no environment variable."""
+    spec = os.environ.get("PRHF_TEST_OPTIONS", "")
+    if spec:
+        from pyrayhf_amd import library
+        for item in spec.split(","):
+            name, value = item.split("=")
+            library.set_option(name.strip(), float(value))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _test_options():
+    if os.environ.get("PRHF_TEST_OPTIONS"):
+        apply_test_options()
+    yield
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name)) as z:
         return {k: z[k] for k in z.files}

@@ -1,6 +1,6 @@
-"""How the default O-mode arithmetic depends on its threshold (PRHF_WELL_CONDITIONED: the reduced algebra where
+"""How the default O-mode arithmetic depends on its threshold (context option "well_conditioned": the reduced algebra where
 1 - X exceeds it, the reference's operation order below): error distribution against the NumPy oracle and kernel time
-per threshold, each in a process of its own (the knob is read when the library loads).
+per threshold, each in a process of its own.
 Usage: python tests/devtools/omode_threshold.py            (driver)
        python tests/devtools/omode_threshold.py worker     (one threshold, from the environment)"""
 import sys, os, json, subprocess
@@ -17,6 +17,8 @@ def inputs():
 if len(sys.argv) > 1 and sys.argv[1] == "worker":
     from pyrayhf_amd import library, _native
     freq, alt, den, bmag, bpsi = inputs()
+    if os.environ.get("SWEEP_WELL_CONDITIONED"):
+        library.set_option("well_conditioned", float(os.environ["SWEEP_WELL_CONDITIONED"]))
     want = np.load(CACHE)
     for n, rows in CASES:
         ms = []
@@ -28,7 +30,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
         ok = np.isfinite(w) & np.isfinite(got)
         err = np.abs(got[ok] - w[ok]) / np.abs(w[ok])
         dref = np.abs(got[ok] - ref[ok]) / np.abs(w[ok])
-        print(json.dumps({"threshold": os.environ.get("PRHF_WELL_CONDITIONED", "default 1e-5"), "n_points": n, "pairs": int(ok.sum()),
+        print(json.dumps({"threshold": os.environ.get("SWEEP_WELL_CONDITIONED", "default 1e-5"), "n_points": n, "pairs": int(ok.sum()),
                           "mask_diffs": int((np.isnan(got) != np.isnan(w)).sum()), "within_1e-6": float((err <= 1e-6).mean()),
                           "p99": float(np.percentile(err, 99)), "max": float(err.max()),
                           "vs_reference_order": {"p99": float(np.percentile(dref, 99)), "max": float(dref.max()), "over_1e-7": int((dref > 1e-7).sum())},
@@ -39,5 +41,5 @@ else:
     np.savez(CACHE, **{f"n{n}": vfo_numpy.virtual_heights_batch(freq, den[:rows], bmag[:rows], bpsi[:rows], alt, "O", n) for n, rows in CASES})
     for wc in (None, "3e-6", "1e-6", "3e-7", "1e-7"):
         env = dict(os.environ)
-        if wc: env["PRHF_WELL_CONDITIONED"] = wc
+        if wc: env["SWEEP_WELL_CONDITIONED"] = wc
         subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=env, check=False)

@@ -26,6 +26,8 @@ window is needed (tests/devtools/omode_report.py prints the counts for every fix
 
 import numpy as np
 
+LIMIT_CAP = 1e-3           # no pair may be off by more than this whatever its recorded noise (a noise floor that is
+                           # infinite - the NaN mask flipped under the jitter - or huge must not switch the check off)
 X_TOL_BASELINE = 1e-4      # BASELINE.json north_star, X mode at high n_points
 X_TOL_TIGHT = 1e-8         # what we actually require
 O_TOL = 1e-6               # BASELINE.json north_star, O mode
@@ -79,8 +81,10 @@ def assert_x_mode(got, want, tol=X_TOL_TIGHT):
     return float(err.max(initial=0.0))
 
 
-def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WITHIN):
-    """The O-mode rule above.  `noise` None: 1e-6 for every pair."""
+def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WITHIN, max_beyond=None):
+    """The O-mode rule above.  `noise` None: 1e-6 for every pair.  The per-pair limit is capped at LIMIT_CAP.
+    `max_beyond`: instead of the share `min_within`, the NUMBER of finite pairs that may miss 1e-6 outright
+    (each still within its own limit) - for small problems, where a share is not a statistic."""
     assert_masks(got, want)
     err, ok = rel_err(got, want)
     if noise is None:
@@ -89,14 +93,18 @@ def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WIT
         noise = np.asarray(noise, dtype=np.float64)
         if noise.ndim > want.ndim:                         # a (1, F) floor for one (F,) profile
             noise = noise.reshape(want.shape)
-        limit = np.maximum(O_TOL, factor * effective_noise(np.broadcast_to(noise, want.shape)))
+        limit = np.minimum(LIMIT_CAP, np.maximum(O_TOL, factor * effective_noise(np.broadcast_to(noise, want.shape))))
     over = ok & (err > limit)
-    assert not over.any(), (f"O-mode: {int(over.sum())} pairs beyond max(1e-6, {factor}*noise); worst "
+    assert not over.any(), (f"O-mode: {int(over.sum())} pairs beyond min({LIMIT_CAP:g}, max(1e-6, {factor}*noise)); worst "
                             f"{err[over].max():.3e} at {np.argwhere(over)[:5].tolist()}")
     n_ok = int(ok.sum())
     if n_ok:
         frac = float((err[ok] <= O_TOL).sum()) / n_ok
-        # a handful of pairs cannot support a 1 % statistic: allow one pair per started 100
-        allowed = max(int(np.ceil((1.0 - min_within) * n_ok)), 1 if n_ok < 100 else 0)
-        assert int((err[ok] > O_TOL).sum()) <= allowed, f"only {frac:.4f} of {n_ok} finite pairs within 1e-6"
+        if max_beyond is not None:
+            allowed = int(max_beyond)
+        else:
+            # a handful of pairs cannot support a 1 % statistic: allow one pair per started 100
+            allowed = max(int(np.ceil((1.0 - min_within) * n_ok)), 1 if n_ok < 100 else 0)
+        assert int((err[ok] > O_TOL).sum()) <= allowed, (f"{int((err[ok] > O_TOL).sum())} of {n_ok} finite pairs beyond 1e-6 "
+                                                        f"(allowed {allowed}; {frac:.4f} within)")
     return float(err.max(initial=0.0))

@@ -1,6 +1,6 @@
-"""The launch-shaping knobs (block queue, tail refinement, chunk target) change which workgroup computes a
-pair and in which order blocks run - never the value of a pair.  Each setting runs in a child process
-(the knobs are read when the library creates its first context) and must reproduce the default bit for bit."""
+"""The launch-shaping options (block queue, tail refinement, the short-grid kernel's queue size and stream) change
+which workgroup computes a pair and in which order blocks run - never the value of a pair.  Each setting runs on a
+fresh set of launches (library.set_option on this thread's context) and must reproduce the default bit for bit."""
 
 import os
 import subprocess
@@ -13,31 +13,35 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, %r)
-from pyrayhf_amd import library, synth
-alt, den, bmag, bpsi = synth.chapman_profiles(700, 4242)
-freq = synth.sounder_frequencies(4)[::4]
-a = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 2000)          # 700 blocks > 512 slots
-b = library.vertical_forward_operator(freq, den[:40], bmag[:40], bpsi[:40], alt, "O", 200)
-np.savez(sys.argv[1], a=a, b=b)
-"""
+DEFAULTS = {"persistent": 1, "tail_bpp": 4, "tail_rounds": 1.0, "short_queue": 0, "short_concurrent": 1}
 
 
-def run_child(tmp_path, tag, env):
-    out = str(tmp_path / f"{tag}.npz")
-    full = dict(os.environ, **env)
-    subprocess.run([sys.executable, "-c", CHILD % ROOT, out], env=full, check=True, timeout=300)
-    return np.load(out)
+def run_with(options):
+    from pyrayhf_amd import library, synth
+    for name, value in {**DEFAULTS, **options}.items():
+        library.set_option(name, value)
+    try:
+        alt, den, bmag, bpsi = synth.chapman_profiles(700, 4242)
+        freq = synth.sounder_frequencies(4)[::4]
+        a = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", 2000)          # 700 blocks > 512 slots
+        b = library.vertical_forward_operator(freq, den[:40], bmag[:40], bpsi[:40], alt, "O", 200)
+        c = library.vertical_forward_operator(freq, den[:200], bmag[:200], bpsi[:200], alt, "O", 200)   # short-grid kernel
+        d = library.vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt,
+                                                    [(0, 300, "O", 200), (300, 500, "X", 2000), (500, 700, "O", 500)])
+    finally:
+        for name, value in DEFAULTS.items():
+            library.set_option(name, value)
+    return {"a": a, "b": b, "c": c, "d": d}
 
 
-def test_knobs_do_not_change_results(tmp_path):
-    base = run_child(tmp_path, "default", {})
-    assert np.isfinite(base["a"]).mean() > 0.3
-    for tag, env in (("no_queue", {"PRHF_PERSISTENT": "0"}),
-                     ("no_tail", {"PRHF_TAIL_BPP": "1"}),
-                     ("long_tail", {"PRHF_TAIL_BPP": "8", "PRHF_TAIL_ROUNDS": "0.25"})):
-        got = run_child(tmp_path, tag, env)
-        for key in ("a", "b"):
+def test_knobs_do_not_change_results():
+    base = run_with({})
+    assert np.isfinite(base["a"]).mean() > 0.3 and np.isfinite(base["c"]).mean() > 0.3
+    for tag, options in (("no_queue", {"persistent": 0}),
+                         ("no_tail", {"tail_bpp": 1}),
+                         ("long_tail", {"tail_bpp": 8, "tail_rounds": 0.25}),
+                         ("short_queue_overflows", {"short_queue": 16}),
+                         ("one_stream", {"short_concurrent": 0})):
+        got = run_with(options)
+        for key in base:
             assert np.array_equal(got[key], base[key], equal_nan=True), (tag, key)

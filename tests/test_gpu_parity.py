@@ -94,6 +94,24 @@ def test_config3_rows_o_mode_g10(lib):
               f"worst {worst:.2e}")
 
 
+def test_config3_rows_against_the_reference_noise_alone_g10(lib):
+    """The same rows under SURVEY 8(d)'s rule as written - |gpu - ref| <= max(1e-6, 4 x the REFERENCE's recorded
+    input-jitter noise), nothing made with the oracle in the floor - as a count: the two pairs that only the
+    rounding noise explains (NumPy's pow is one ulp off there, DESIGN.md section 2: 1.4e-6 and 4.2e-6 against an
+    input noise of 1e-11) are the only ones allowed beyond it, and they stay below 1e-5.  A regression of the
+    exactly rounded sin / cos / pow path cannot hide behind an oracle-made floor here."""
+    g = load_golden("g10_config3_rows.npz")
+    want = g["O_200_vh"]
+    limit = np.minimum(1e-3, np.maximum(1e-6, 4.0 * np.where(np.isfinite(g["O_200_noise"]), g["O_200_noise"], np.inf)))
+    for math in (None, lib.MATH_FAITHFUL):
+        vo = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 200, math=math)
+        assert_masks(vo, want)
+        err, ok = rel_err(vo, want)
+        beyond = ok & (err > limit)
+        assert int(beyond.sum()) <= 2 and err[beyond].max(initial=0.0) <= 1e-5, (math, int(beyond.sum()), err[beyond])
+        assert (err[ok] <= 1e-6).mean() >= 0.998, (math, (err[ok] <= 1e-6).mean())
+
+
 @pytest.mark.parametrize("math", ["faithful", "fast"])
 def test_both_tiers_both_modes(lib, math):
     """Every (tier, mode) combination against the reference vectors, not just the defaults."""
@@ -194,9 +212,43 @@ def test_error_behaviour(lib):
         lib.vertical_forward_operator(g["freq"], g["den"][::-1].copy(), g["bmag"], g["bpsi"], g["alt"], "O", 10)
     with pytest.raises(ValueError):
         lib.vertical_forward_operator(g["freq"], g["den"][:2], g["bmag"], g["bpsi"], g["alt"], "O", 10)
-    for bad_f in (0.0, -3.0, np.nan, np.inf):              # stricter than the reference, which returns NaN / garbage
-        with pytest.raises(ValueError, match="positive finite"):
-            lib.vertical_forward_operator(np.array([2.0, bad_f]), g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    # a frequency that is not a positive finite number: a NaN column and the other columns untouched, NumPy and
+    # GPU-resident inputs alike (the reference: NaN for 0 and NaN - a sweep padded with NaN works there too - and
+    # something meaningless for a negative frequency)
+    import torch
+    clean = lib.vertical_forward_operator(np.array([2.0, 3.0]), g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 10)
+    for mode, n in (("O", 10), ("X", 10), ("O", 200), ("X", 2000)):
+        clean = lib.vertical_forward_operator(np.array([2.0, 3.0]), g["den"], g["bmag"], g["bpsi"], g["alt"], mode, n)
+        for bad_f in (0.0, -3.0, np.nan, np.inf):
+            f = np.array([2.0, bad_f, 3.0])
+            vh = lib.vertical_forward_operator(f, g["den"], g["bmag"], g["bpsi"], g["alt"], mode, n)
+            assert np.isnan(vh[1]) and np.array_equal(vh[[0, 2]], clean, equal_nan=True), (mode, n, bad_f, vh)
+            t = [torch.as_tensor(x, device="cuda:0") for x in (f, g["den"], g["bmag"], g["bpsi"], g["alt"].astype(float))]
+            vt = lib.vertical_forward_operator(*t, mode, n).cpu().numpy()
+            assert np.array_equal(vt, vh, equal_nan=True), (mode, n, bad_f)
+    # ... also in a batch that takes the long-launch paths (candidate list, short-grid kernel)
+    g5 = load_golden("g5_chapman64.npz")
+    f = g5["freq"].copy()
+    f[[7, 60]] = [np.nan, -1.0]
+    for mode, n in (("O", 200), ("X", 2000)):
+        vh = lib.vertical_forward_operator(f, g5["den"], g5["bmag"], g5["bpsi"], g5["alt"], mode, n)
+        want = lib.vertical_forward_operator(g5["freq"], g5["den"], g5["bmag"], g5["bpsi"], g5["alt"], mode, n)
+        keep = np.ones(f.size, bool)
+        keep[[7, 60]] = False
+        assert np.isnan(vh[:, ~keep]).all() and np.array_equal(vh[:, keep], want[:, keep], equal_nan=True), mode
+    # NaN in a profile is an error (the reference lets np.argmax / np.interp spread it over the whole profile)
+    for col in ("den", "alt", "bmag", "bpsi"):
+        for n, mode in ((10, "O"), (200, "O"), (2000, "X")):
+            bad = {k: g5[k].copy() for k in ("den", "bmag", "bpsi")}
+            alt5 = np.tile(g5["alt"], (64, 1))
+            (alt5 if col == "alt" else bad[col])[11, 3] = np.nan         # level 3: below every peak
+            with pytest.raises(ValueError, match="NaN in a profile"):
+                lib.vertical_forward_operator(g5["freq"], bad["den"], bad["bmag"], bad["bpsi"], alt5, mode, n)
+    top = g5["bmag"].copy()
+    top[:, -1] = np.nan                                                  # above the peak: never read, as in the reference
+    ok_vh = lib.vertical_forward_operator(g5["freq"], g5["den"], top, g5["bpsi"], g5["alt"], "X", 2000)
+    assert np.array_equal(ok_vh, lib.vertical_forward_operator(g5["freq"], g5["den"], g5["bmag"], g5["bpsi"], g5["alt"], "X", 2000),
+                          equal_nan=True)
     # the context stays usable after a data error
     vh = lib.vertical_forward_operator(*args, "O", 50)
     assert np.isfinite(vh[0])
@@ -452,9 +504,18 @@ def test_more_frequencies_than_the_candidate_list_holds(lib):
     long_ = lib.vertical_forward_operator(freq, g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
     head = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
     assert np.array_equal(long_[:, :1000], head, equal_nan=True)
+    # O mode, n_points = 200: 1000 frequencies go to the short-grid kernel, 1100 (more than its list holds) to the
+    # general one - which chooses between its two formulations per wave-iteration, not per point: ~1e-10 apart
     lo = lib.vertical_forward_operator(freq, g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "O", 200)
     ho = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "O", 200)
-    # O mode, n_points = 200: four frequencies share a tail iteration, but the tail is evaluated point by point in
-    # the reference's order - grouping does not change a value
-    assert np.array_equal(lo[:, :1000], ho, equal_nan=True)
+    assert_masks(lo[:, :1000], ho)
+    err, ok = rel_err(lo[:, :1000], ho)
+    assert err.max() <= 1e-8, err.max()
+    # ... and inside the general kernel the list changes nothing, bit for bit
+    lib.set_option("short_kernel", 0)
+    try:
+        ho_general = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "O", 200)
+    finally:
+        lib.set_option("short_kernel", 1)
+    assert np.array_equal(lo[:, :1000], ho_general, equal_nan=True)
     assert 0.3 < np.isfinite(long_).mean() < 0.8

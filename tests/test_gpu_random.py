@@ -60,7 +60,7 @@ def test_random_problems_against_c_oracle(seed):
         want_x = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, "X", n_points)
         with np.errstate(all="ignore"):
             want_o = vfo_numpy.virtual_heights_batch(freq, den, bmag, bpsi, alt, "O", n_points)
-        noise = oracle_noise(freq, den, bmag, bpsi, alt, "O", n_points, runs=8, seed=seed)
+        noise = oracle_noise(freq, den, bmag, bpsi, alt, "O", n_points, runs=24, seed=seed)
         for tier in (None, library.MATH_FAITHFUL, library.MATH_FAST):
             got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n_points, math=tier)
             assert got.shape == want_x.shape
@@ -78,7 +78,9 @@ def test_random_problems_against_c_oracle(seed):
             else:
                 # the default arithmetic and the reference order everywhere: per pair, max(1e-6, 4 x noise)
                 try:
-                    assert_o_mode(got, want_o, noise, min_within=0.9)
+                    # (count rule: at most max(1, 1 %) of a problem's finite pairs may miss 1e-6 outright)
+                    n_fin = int(np.isfinite(want_o).sum())
+                    assert_o_mode(got, want_o, noise, max_beyond=max(1, n_fin // 100))
                 except AssertionError as exc:
                     raise AssertionError(f"seed {seed} tier {tier} n_points {n_points}: {exc}") from None
             checked += 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the short-grid kernel against the general kernel on the same box (PRHF_SHORT_KERNEL=1 / 0, one child
-process each: the knob is read when the context is created): kernel time of BASELINE config 3 and of the
+"""A/B of the short-grid kernel against the general kernel on the same box (context options short_kernel,
+short_queue, short_concurrent; one child process each): kernel time of BASELINE config 3 and of the
 config-5 shard, and how far the two outputs are apart.  Usage: python tools/ab_short.py [n_prof]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,8 @@ def child(tag, n_prof):
     from pyrayhf_amd import library, synth, _native, dist as pdist
     dev = torch.device("cuda", 0)
     ctx = _native.context(0)
+    for item in os.environ["AB_OPTIONS"].split(","):
+        ctx.set_option(item.split("=")[0], float(item.split("=")[1]))
     f174 = synth.sounder_frequencies(1)
     alt, den, bmag, bpsi = synth.chapman_profiles(n_prof, 20260003)
     t = [torch.as_tensor(x, device=dev) for x in (f174, den, bmag, bpsi, alt)]
@@ -44,7 +46,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
 n_prof = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 for tag, knob, qfix, conc in (("general", "0", "0", "1"), ("short", "1", "0", "1"), ("tinyq", "1", "40", "1"),
                               ("sequential", "1", "0", "0")):
-    env = dict(os.environ, PRHF_SHORT_KERNEL=knob, PRHF_SHORT_QUEUE=qfix, PRHF_SHORT_CONCURRENT=conc)
+    env = dict(os.environ, AB_OPTIONS=f"short_kernel={knob},short_queue={qfix},short_concurrent={conc}")
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", tag, str(n_prof)], env=env, check=True)
 for key in ("n200", "n500", "n1000", "c5"):
     b = np.load(os.path.join(ROOT, "gpurun_out", f"ab_short_short_{key}.npy"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""How much slower are the less regular inputs: a non-uniform altitude grid (main loop with the segment lookup
-through the hint table) and a field angle that turns too fast for the per-segment polynomial (generic loop)."""
+"""How much slower are the less regular inputs: a non-uniform altitude grid (main loop with a monotone segment cursor),
+a field angle that turns too fast for the per-segment polynomial (main loop with the rotation form) and one that turns
+by more than 0.05 rad per level (sin per point, generic loop)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,8 +30,11 @@ def run(name, alt, den, bmag, bpsi, mode="X", n=20000):
 
 run("uniform grid, slowly turning field (main loop)", alt_u, den, bmag, bpsi)
 alt_n = 80.0 + np.concatenate([[0.0], np.cumsum(rng.uniform(0.5, 1.5, alt_u.size - 1))])
-run("non-uniform grid (main loop through the hint table)", alt_n, *chap(alt_n))
+run("non-uniform grid (main loop, segment cursor)", alt_n, *chap(alt_n))
 d2, b2, p2 = chap(alt_u)
-run("field angle turning 0.05 deg/km (sin per point, generic loop)", alt_u, d2, b2, p2 + 0.05 * (alt_u[None] - 80.0))
+run("field angle turning 0.05 deg/km (main loop, rotation form)", alt_u, d2, b2, p2 + 0.05 * (alt_u[None] - 80.0))
+run("field angle turning 1 deg/km (main loop, rotation form)", alt_u, d2, b2, p2 + 1.0 * (alt_u[None] - 80.0))
+run("field angle turning 4 deg/km (sin per point, generic loop)", alt_u, d2, b2, p2 + 4.0 * (alt_u[None] - 80.0))
+run("non-uniform grid and a field angle turning 0.05 deg/km", alt_n, *[x if i < 2 else x + 0.05 * (alt_n[None] - 80.0) for i, x in enumerate(chap(alt_n))])
 run("O mode default, uniform grid", alt_u, den, bmag, bpsi, mode="O")
 run("O mode default, non-uniform grid", alt_n, *chap(alt_n), mode="O")

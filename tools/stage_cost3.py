@@ -1,10 +1,13 @@
 """Cost split of config 3 (10 000 profiles x 174 freqs, O mode, n_points = 200): staging, level scan,
-integration by arithmetic setting and grid size.  PRHF_WELL_CONDITIONED etc. are read from the environment."""
+integration by arithmetic setting and grid size.  PRHF_TOOL_OPTIONS="name=value,..." sets context options (tools/_options.py)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from pyrayhf_amd import library, synth, _native
 dev = torch.device("cuda", 0); ctx = _native.context(0)
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import _options
+OPTIONS = _options.apply()
 alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
 t = [torch.as_tensor(x, device=dev) for x in (den, bmag, bpsi, alt)]
 def run(name, freq, n_points=200, math=None, mode="O"):
@@ -13,7 +16,7 @@ def run(name, freq, n_points=200, math=None, mode="O"):
     for r in range(5):
         out = library.vertical_forward_operator(f, *t, mode, n_points, math=math); ms.append(ctx.last_kernel_ms())
     print(json.dumps({"case": name, "kernel_ms": min(ms[1:]), "finite": float(np.isfinite(out.cpu().numpy()).mean()),
-                      "env": {k: v for k, v in os.environ.items() if k.startswith("PRHF_")}}), flush=True)
+                      "options": OPTIONS}), flush=True)
 f174 = synth.sounder_frequencies(3)
 run("staging only: 1 escaping frequency", [30.0])
 run("174 certainly escaping frequencies (no scan)", np.full(174, 30.0))

@@ -13,5 +13,15 @@ for mode, n in (("O", 200), ("X", 200), ("O", 2000), ("X", 20000)):
     for _ in range(reps):
         vh = library.vertical_forward_operator(freq, den[0], bmag[0], bpsi[0], alt, mode, n)
     dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({"call": f"vertical_forward_operator(174 freqs, 1 profile, '{mode}', {n}) on NumPy arrays", "us_per_call": 1e6 * dt,
+    # the same call with the foreign function replaced by a no-op: what the Python binding itself costs
+    from pyrayhf_amd import _native
+    ctx = _native.host_context(None)
+    real = ctx.vfo_batch
+    ctx.vfo_batch = lambda *a, **k: 0
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        library.vertical_forward_operator(freq, den[0], bmag[0], bpsi[0], alt, mode, n)
+    binding = (time.perf_counter() - t1) / reps
+    ctx.vfo_batch = real
+    print(json.dumps({"call": f"vertical_forward_operator(174 freqs, 1 profile, '{mode}', {n}) on NumPy arrays", "us_per_call": 1e6 * dt, "python_binding_us": 1e6 * binding,
                       "kernel_us": 1e3 * library.last_kernel_ms(), "finite": int(np.isfinite(vh).sum())}), flush=True)
