@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--math", default=None, choices=[None, "faithful", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-profile", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a context option of the library (prhf_ctx_set_option), e.g. shortx_kernel=0: A/B measurements")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the extra driver-timed legs (config3, config5_shard, config4_full) of the default run")
     ap.add_argument("--force-collective", action="store_true",
@@ -319,6 +321,8 @@ def main():
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
     ctx = _native.context(local_rank)
+    for item in args.option:
+        ctx.set_option(item.split("=")[0], float(item.split("=")[1]))
 
     # ---- the workload: this rank's rows of the BASELINE configuration ------------------------------
     if args.workload == "config5":
@@ -413,10 +417,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         # every rank's mean kernel time and gather time, so that a scaling loss can be attributed
-        mine = torch.tensor([float(np.mean(kernel_ms)), gather_ms or 0.0], dtype=torch.float64, device=side)
-        every = torch.empty((world_seen, 2), dtype=torch.float64, device=side)
-        dist.all_gather_into_tensor(every, mine)
-        every = every.cpu().numpy()
+        every = pdist.gather_scalars([float(np.mean(kernel_ms)), gather_ms or 0.0], device=side)
         kernel_ms_per_rank = {"min": float(every[:, 0].min()), "max": float(every[:, 0].max()),
                               "ranks": [float(v) for v in every[:, 0]]}
         gather_ms = float(every[:, 1].max())

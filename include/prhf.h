@@ -102,7 +102,8 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  * -DPRHF_DIAG build presets these from PRHF_<NAME> at context creation.  PRHF_EINVAL for an unknown name or a
  * value outside the option's range.
  *   "well_conditioned"   default O-mode arithmetic: the reference's operation order where 1 - X <= this (1e-5)
- *   "short_kernel"       0: short O-mode grids (65 .. 1024 points) stay in the general kernel (1)
+ *   "short_kernel"       0: short O-mode grids (2 .. 1024 points) stay in the general kernel (1)
+ *   "shortx_kernel"      0: X-mode grids of 2 .. 1024 points (fast tier) stay in the general kernel (1)
  *   "short_concurrent"   0: a mixed list runs its short-grid and general launches one after the other (1)
  *   "short_queue"        > 0: the short-grid kernel's queue of ill-conditioned points holds exactly this many entries (0)
  *   "persistent", "tail_bpp", "tail_rounds", "split_few_profiles", "split_min_points", "target_waves"

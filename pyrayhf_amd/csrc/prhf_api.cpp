@@ -56,6 +56,7 @@ struct Knobs {
     double split_min_points = 1024;    // few-profile slices are cut into several workgroups per profile from this grid size
     double split_few_profiles = 1;     // 0: one workgroup per profile whatever their number
     double short_kernel = 1;           // 0: short O-mode grids stay in the general kernel
+    double shortx_kernel = 1;          // 0: X-mode grids of up to 4096 points stay in the general kernel
     double short_concurrent = 1;       // 0: short-grid and general launch of a mixed list one after the other
     double short_queue = 0;            // > 0: the short-grid kernel's queue holds exactly this many entries (tests)
 };
@@ -76,6 +77,7 @@ const KnobName kKnobNames[] = {
     {"split_min_points", &Knobs::split_min_points, 1, 1e9},
     {"split_few_profiles", &Knobs::split_few_profiles, 0, 1},
     {"short_kernel", &Knobs::short_kernel, 0, 1},
+    {"shortx_kernel", &Knobs::shortx_kernel, 0, 1},
     {"short_concurrent", &Knobs::short_concurrent, 0, 1},
     {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
 };
@@ -153,10 +155,11 @@ struct prhf_ctx {
     DevBuf ftab;      // per-frequency scalars of a long launch
     DevBuf levels;    // level table of a grouped tracer launch
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
+    DevBuf leftover_x;   // ... of the X-mode short-grid launch
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
-    unsigned* d_status = nullptr;   // device words [1..3]: block queues of persistent launches (general, short-grid, its
-                                    // follow-up); [0] unused
+    unsigned* d_status = nullptr;   // device words [1..5]: block queues of persistent launches (general, short-grid O and its
+                                    // follow-up, short-grid X and its follow-up); [0] unused
     unsigned* h_status = nullptr;   // PRHF_STATUS_WORDS words of pinned host memory mapped into the device: word b = status
     unsigned* h_status_dev = nullptr;   // bit b (post_status) - nothing to copy back or reset on the device; its device address
     double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece; its upper
@@ -288,7 +291,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     const Knobs& kn = c->knobs;
     const double kWellConditioned = kn.well_conditioned, kThreadScanMinWork = kn.thread_scan_min;
     const int kLeanMinPoints = (int)kn.lean_min_points, kNoCandidates = kn.no_candidates != 0;
-    const bool kPersistent = kn.persistent != 0, kShortKernel = kn.short_kernel != 0;
+    const bool kPersistent = kn.persistent != 0, kShortKernel = kn.short_kernel != 0, kShortXKernel = kn.shortx_kernel != 0;
     const bool kShortConcurrent = kn.short_concurrent != 0;
     const int kShortQueueFixed = (int)kn.short_queue;
     const int n_user_segs = n_segs;
@@ -298,8 +301,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     a.n_alt = n_alt;
     a.n_segs = n_segs;
     // Slices of short O-mode grids leave for a launch of their own (vfo_short_kernel): `a` keeps the others
-    prhf::SegDev short_seg[PRHF_MAX_SEGMENTS];
-    int n_short = 0;
+    prhf::SegDev short_seg[PRHF_MAX_SEGMENTS], shortx_seg[PRHF_MAX_SEGMENTS];
+    int n_short = 0, n_shortx = 0;
     // LDS budget of a short-grid workgroup: two per CU where its nodes allow that, else one (a few hundred bytes of
     // static LDS - tickets, counters - come on top)
     const size_t lds_half = 80 * 1024 - 512, lds_full = 160 * 1024 - 512;
@@ -358,12 +361,23 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             const prhf::SegDev& s = a.seg[i];
             // the short-grid kernel reads the per-frequency table (launches of >= 4096 pairs) and lists at most
             // PRHF_MAX_CAND frequencies per profile
-            const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && s.lean && s.chunks == 1 &&
+            // (grids shorter than the general kernel's main loop takes - lean_min_points - are theirs too: the pair
+            //  table is built for them)
+            const long long slice_pairs = (s.prof_end - s.prof_begin) * n_freq;
+            const bool table = s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints);
+            const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && table && s.chunks == 1 &&
                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
                                   n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && short_queue > 0;
-            if (is_short) {
-                prhf::SegDev& t = short_seg[n_short++];
+            // ... and its X-mode variant (fast tier, reflection heights per thread, no top-segment phase)
+            const bool is_shortx = kShortXKernel && s.tier == 1 && s.mode == PRHF_KMODE_X && table && s.chunks == 1 &&
+                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORTX_MAX_POINTS &&
+                                   n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && s.thread_scan &&
+                                   prhf::shortx_lds_bytes(n_alt, n_freq) <= lds_full;
+            if (is_short || is_shortx) {
+                prhf::SegDev& t = is_short ? short_seg[n_short++] : shortx_seg[n_shortx++];
                 t = s;
+                t.lean = 1;
+                want_pairs = true;
                 t.blocks_per_prof = 1;
                 t.tail_prof = t.prof_end - t.prof_begin;
                 t.tail_bpp = 1;
@@ -543,8 +557,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 #endif
     a.n_blocks = blocks;
     a.no_candidates = kNoCandidates;
-    if (n_short > 0 || (kPersistent && blocks > wg_slots))
-        HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 3 * sizeof(unsigned), c->stream));     // the launches' block queues
+    if (n_short > 0 || n_shortx > 0 || (kPersistent && blocks > wg_slots))
+        HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 5 * sizeof(unsigned), c->stream));     // the launches' block queues
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
     // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
@@ -559,71 +573,83 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
         return PRHF_OK;
     };
-    const bool forked = n_short > 0 && blocks > 0 && kShortConcurrent;
+    const bool any_short = n_short > 0 || n_shortx > 0;
+    const bool forked = any_short && blocks > 0 && kShortConcurrent;
     hipStream_t short_stream = forked ? c->aux_stream : c->stream;
     if (forked) {
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));        // tables, queues and inputs are in place
         HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->fork_ev, 0));
         if ((rc = launch_general()) != PRHF_OK) return rc;
     }
-    if (n_short > 0) {
-        // Short O-mode grids: vfo_short_kernel, then the general kernel over the profiles it left on its list
-        // (non-uniform altitude grid, fast-turning or vanishing field, negative density, peak at level 0 or 1)
+    // Short grids: vfo_short_kernel (O mode) / vfo_shortx_kernel (X mode), each followed by the general kernel over the
+    // profiles it left on its list (non-uniform altitude grid, fast-turning or vanishing field, negative density,
+    // peak at level 0 or 1, a sum that is not finite)
+    auto launch_short_kind = [&](bool xmode) -> int {
+        const int n_kind = xmode ? n_shortx : n_short;
+        if (n_kind == 0) return PRHF_OK;
+        prhf::SegDev* kind_seg = xmode ? shortx_seg : short_seg;
         prhf::KArgs as = a;
-        as.n_segs = n_short;
+        as.n_segs = n_kind;
         long long short_blocks = 0;
-        for (int i = 0; i < n_short; ++i) {
-            short_seg[i].block_begin = short_blocks;
-            short_blocks += short_seg[i].prof_end - short_seg[i].prof_begin;
-            as.seg[i] = short_seg[i];
+        for (int i = 0; i < n_kind; ++i) {
+            kind_seg[i].block_begin = short_blocks;
+            short_blocks += kind_seg[i].prof_end - kind_seg[i].prof_begin;
+            as.seg[i] = kind_seg[i];
         }
         if (short_blocks > 0x7fffffffLL) return fail(PRHF_EINVAL, "launch too large");
+        if (short_blocks == 0) return PRHF_OK;
         as.n_blocks = short_blocks;
         as.short_queue = kShortQueueFixed > 0 ? -std::min(kShortQueueFixed, short_queue) : short_queue;
         as.partial = nullptr;
         as.altmin = nullptr;
         as.trace = nullptr;
+        as.queue = nullptr;
 #ifdef PRHF_TRACE
         static DevBuf trace_short;
         const size_t short_trace_words = (size_t)short_blocks * kWavesPerBlock * 8;
-        if (std::getenv("PRHF_TRACE_FILE") && short_blocks > 0) {
-            if ((rc = ensure(c, trace_short, short_trace_words * 8)) != PRHF_OK) return rc;
+        if (std::getenv("PRHF_TRACE_FILE") && !xmode) {
+            int rct;
+            if ((rct = ensure(c, trace_short, short_trace_words * 8)) != PRHF_OK) return rct;
             HIP_TRY(hipMemsetAsync(trace_short.p, 0, short_trace_words * 8, short_stream));
             as.trace = static_cast<unsigned long long*>(trace_short.p);
         }
 #endif
-        if (short_blocks > 0) {
-            if ((rc = ensure(c, c->leftover, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rc;
-            as.leftover = static_cast<unsigned*>(c->leftover.p);
-            HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
-            const long long short_slots = (long long)c->cu_count * (short_budget == lds_half ? 2 : 1);
-            long long grid_short = short_blocks;
-            as.queue = nullptr;
-            if (short_blocks > short_slots) {
-                as.queue = c->d_status + 2;
-                grid_short = short_slots;
-            }
-            HIP_TRY(prhf::launch_vfo_short(as, grid_short, prhf::short_lds_fixed(n_alt, n_freq) + 8 * (size_t)short_queue,
-                                           short_stream));
-#ifdef PRHF_TRACE
-            if (as.trace) {                        // eight wall-clock marks per wave and block (tools/wave_trace_short.py)
-                std::vector<unsigned long long> host(short_trace_words);
-                HIP_TRY(hipMemcpyAsync(host.data(), as.trace, short_trace_words * 8, hipMemcpyDeviceToHost, short_stream));
-                HIP_TRY(hipStreamSynchronize(short_stream));
-                if (FILE* fp = std::fopen(std::getenv("PRHF_TRACE_FILE"), "wb")) {
-                    std::fwrite(host.data(), 8, short_trace_words, fp);
-                    std::fclose(fp);
-                }
-            }
-#endif
-            prhf::KArgs af = as;
-            af.trace = nullptr;
-            af.block_list = as.leftover;
-            af.leftover = nullptr;
-            af.queue = c->d_status + 3;
-            HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), 0, prhf::lds_bytes_for(n_alt), short_stream));
+        DevBuf& left = xmode ? c->leftover_x : c->leftover;
+        int rcl;
+        if ((rcl = ensure(c, left, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
+        as.leftover = static_cast<unsigned*>(left.p);
+        HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
+        const size_t lds = xmode ? prhf::shortx_lds_bytes(n_alt, n_freq)
+                                 : prhf::short_lds_fixed(n_alt, n_freq) + 8 * (size_t)short_queue;
+        const long long short_slots = (long long)c->cu_count * (lds <= lds_half ? 2 : 1);
+        long long grid_short = short_blocks;
+        if (short_blocks > short_slots) {
+            as.queue = c->d_status + (xmode ? 4 : 2);
+            grid_short = short_slots;
         }
-    }
+        if (xmode) HIP_TRY(prhf::launch_vfo_shortx(as, grid_short, lds, short_stream));
+        else HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, short_stream));
+#ifdef PRHF_TRACE
+        if (as.trace) {                            // eight wall-clock marks per wave and block (tools/wave_trace_short.py)
+            std::vector<unsigned long long> host(short_trace_words);
+            HIP_TRY(hipMemcpyAsync(host.data(), as.trace, short_trace_words * 8, hipMemcpyDeviceToHost, short_stream));
+            HIP_TRY(hipStreamSynchronize(short_stream));
+            if (FILE* fp = std::fopen(std::getenv("PRHF_TRACE_FILE"), "wb")) {
+                std::fwrite(host.data(), 8, short_trace_words, fp);
+                std::fclose(fp);
+            }
+        }
+#endif
+        prhf::KArgs af = as;
+        af.trace = nullptr;
+        af.block_list = as.leftover;
+        af.leftover = nullptr;
+        af.queue = c->d_status + (xmode ? 5 : 3);
+        HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), xmode ? 1 : 0, prhf::lds_bytes_for(n_alt), short_stream));
+        return PRHF_OK;
+    };
+    if ((rc = launch_short_kind(true)) != PRHF_OK) return rc;          // (the longer blocks first)
+    if ((rc = launch_short_kind(false)) != PRHF_OK) return rc;
     if (forked) {
         HIP_TRY(hipEventRecord(c->join_ev, c->aux_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
@@ -701,11 +727,11 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 4 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 8 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), PRHF_STATUS_WORDS * sizeof(unsigned),
                            hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_status_dev), c->h_status, 0)) != hipSuccess ||
-        (e = hipMemset(c->d_status, 0, 4 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_status, 0, 8 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocMapped | hipHostMallocCoherent)) !=
             hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_pack_dev), c->h_pack, 0)) != hipSuccess ||
@@ -743,6 +769,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->ftab.p) (void)hipFree(c->ftab.p);
     if (c->levels.p) (void)hipFree(c->levels.p);
     if (c->leftover.p) (void)hipFree(c->leftover.p);
+    if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_pack) (void)hipHostFree(c->h_pack);

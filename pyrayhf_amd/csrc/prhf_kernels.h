@@ -25,12 +25,17 @@
 #define PRHF_RED_DOUBLES 160        // block-reduction scratch (9 rows x up to 16 waves) + per-profile scalars
 #define PRHF_NODE_BYTES 96          // one staged bottomside level
 #define PRHF_SNODE_BYTES 80         // ... of the short-grid kernel (20 dwords: conflict-free under ds_read_b128)
-#define PRHF_SHORT_MIN_POINTS 65    // grids of 65 .. 1024 points in the default O-mode arithmetic: vfo_short_kernel
+#define PRHF_SHORT_MIN_POINTS 2     // grids of 2 .. 1024 points in the default O-mode arithmetic: vfo_short_kernel
 #define PRHF_SHORT_MAX_POINTS 1024  // (16 wave-iterations: one violation mask each, per wave)
+#define PRHF_SHORTX_MAX_POINTS 1024  // X mode (fast tier) up to this many points: vfo_shortx_kernel (no top-segment phase;
+                                    // measured against the general kernel: -38 % at 200 points, -21 % at 500, -7 % at 1000, +6 % at 2000)
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
 #define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
 #ifndef PRHF_TOP_MIN_POINTS
 #define PRHF_TOP_MIN_POINTS 1024    // grids from this many points on give their top segment a loop of its own
+#endif
+#ifndef PRHF_TOP3_MIN_POINTS
+#define PRHF_TOP3_MIN_POINTS 8192   // ... and from this many on, the two segments below it as well
 #endif
 #ifndef PRHF_MIN_WAVES_PER_SIMD
 #define PRHF_MIN_WAVES_PER_SIMD 4   // two 8-wave workgroups per CU: caps VGPRs at 128
@@ -110,6 +115,15 @@ inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_f
 inline size_t short_lds_fixed(long long n_alt, long long n_freq) {
     return short_lds_lists(n_alt, n_freq) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
 }
+// ... of the X-mode variant (vfo_shortx_kernel): no queue; f_N^2 and g_p |B| per level, three doubles and an index
+// per frequency, scratch, nodes
+inline __host__ __device__ size_t shortx_lds_lists(long long n_alt, long long n_freq) {
+    const size_t b = (size_t)n_alt * 16 + (size_t)n_freq * 24 + PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 2;
+    return (b + 15) & ~(size_t)15;
+}
+inline size_t shortx_lds_bytes(long long n_alt, long long n_freq) {
+    return shortx_lds_lists(n_alt, n_freq) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
+}
 // queue entries that fit `budget` bytes beside a full node table (0: the kernel cannot run)
 inline int short_queue_entries(long long n_alt, long long n_freq, size_t budget) {
     const size_t fixed = short_lds_fixed(n_alt, n_freq);
@@ -131,6 +145,8 @@ hipError_t launch_vfo(const KArgs& a, long long grid_blocks, int tier, size_t ld
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
+// the X-mode variant; lds_bytes = shortx_lds_bytes
+hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
                          unsigned long long* absmax_scratch, unsigned long long* absmax_host,

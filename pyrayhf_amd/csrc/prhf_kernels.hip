@@ -973,55 +973,72 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     };
     // whole iterations: all 64 points below `end` and none of them the special last point
     const int whole_end = first + (((last_special >= 0 ? last_special : end) - first) & ~63);
-    // Long loops on a uniform grid: from grid point i_top on, every point lies in the segment of the last one
-    // (lean_step_top).  i_top = first i with m_i >= j_top / kj, found in the (monotone) pair table by a 64-ary
-    // search: three rounds of one load and one ballot for 20 000 points.
-    int split = whole_end;                             // [first, split): indexed steps, [split, ...): top-segment steps
+    // Long loops: the stretched grid is dense near the reflection height - ~43 % of a 20 000-point grid lies in the
+    // segment of the last point, another ~11 % and ~5 % in the two segments below it.  For the whole wave-iterations
+    // inside one of these top kTopSegments segments the node is the same for every lane and every trip
+    // (lean_step_top): no segment index, no LDS read.  The first grid point of segment j - the first i with
+    // m_i >= m_star(j), the grid position of its left end: j / kj on a uniform altitude grid, else from the node's own
+    // offset alt_0 - alt_j - is found in the (monotone) pair table by a 64-ary search: three rounds of one load and
+    // one ballot for 20 000 points.  What lies between two such runs - the wave-iteration that straddles a level -
+    // and everything below them takes the indexed steps.
+    constexpr int kTopSegments = 3;
+    static_assert(kTopSegments == 3, "the run loop below selects among three");
+    int seg_begin[kTopSegments] = {0, 0, 0}, seg_end[kTopSegments] = {0, 0, 0}, seg_j[kTopSegments] = {0, 0, 0};   // [0]: the top segment
+    int n_seg = 0;
     TopSegment top;
     __builtin_memset(&top, 0, sizeof top);
-    bool top_phase = false;
     if (TOP && end - first >= PRHF_TOP_MIN_POINTS) {
         const int i_last = (last_special >= 0 ? last_special : end - 1);
         const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, i_last * (int)sizeof(double2), 0);
         double2 gl;
         __builtin_memcpy(&gl, &vl, sizeof gl);
-        // the segment of the last point and the grid position m_star of its left end: closed form on a uniform altitude
-        // grid; through the hint table and the node's own offset (alt_0 - alt_j) otherwise
-        int j_top;
-        double m_star;
-        if (HINT) {
-            j_top = uniform(cursor_at(gl.x, span, a0v, kj, nodes_v, hint_v).j);
-            typedef __attribute__((address_space(3))) const double* LdsDouble;
-            const double off_top = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j_top, (unsigned)sizeof(Node)) + 8u);
-            m_star = uniform(-off_top / span);
-        } else {
-            j_top = uniform((int)(gl.x * kj));
-            m_star = uniform((double)j_top / kj);
-        }
-        int lo = first, hi = i_last + 1;               // the answer lies in [lo, hi): m[hi - 1] >= m_star
-        bool found = uniform((int)(gl.x >= m_star)) != 0;
-        while (found && hi - lo > 1) {
-            const int stride = (hi - lo + 63) >> 6;
-            const int probe = min(lo + (lane + 1) * stride - 1, hi - 1);
-            const u32x4 vp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)probe * (unsigned)sizeof(double2), 0, 0);
-            double2 gp;
-            __builtin_memcpy(&gp, &vp, sizeof gp);
-            const unsigned long long hit = __ballot(gp.x >= m_star);
-            if (!hit) { found = false; break; }
-            const int L = __ffsll((long long)hit) - 1;
-            const int nlo = lo + L * stride;
-            hi = min(nlo + stride, hi);
-            lo = nlo;
-        }
-        if (found) {
-            const int aligned = first + ((lo - first + 63) & ~63);
-            if (aligned + 128 <= whole_end) {          // worth a second loop
-                split = aligned;
-                top = top_segment(nodes_v, j_top, span, uniform(sqrt(hcY2)));     // Y / sqrt(2) = g_p |B| / (sqrt(2) f)
-                top_phase = true;
+        const int j_top = HINT ? uniform(cursor_at(gl.x, span, a0v, kj, nodes_v, hint_v).j) : uniform((int)(gl.x * kj));
+        int search_hi = i_last + 1;                    // m[search_hi - 1] >= m_star of the segment searched next
+        int run_end = whole_end;                       // whole wave-iterations of that segment end here
+        // (the two segments below the top one hold ~16 % of the points: worth their searches - three dependent loads
+        //  each - on long grids only; measured: +5 % on 2000 points, -2.6 % on 20 000)
+        const int max_seg = (end - first) >= PRHF_TOP3_MIN_POINTS ? kTopSegments : 1;
+#pragma unroll
+        for (int sidx = 0; sidx < kTopSegments; ++sidx) {
+            const int j = j_top - sidx;
+            if (j < 0 || n_seg != sidx || sidx >= max_seg) break;
+            double m_star;
+            if (HINT) {
+                typedef __attribute__((address_space(3))) const double* LdsDouble;
+                const double off_j = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)) + 8u);
+                m_star = uniform(-off_j / span);
+            } else {
+                m_star = uniform((double)j / kj);
             }
+            int lo = first, hi = search_hi;            // the answer lies in [lo, hi)
+            bool found = true;
+            while (hi - lo > 1) {
+                const int stride = (hi - lo + 63) >> 6;
+                const int probe = min(lo + (lane + 1) * stride - 1, hi - 1);
+                const u32x4 vp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)probe * (unsigned)sizeof(double2), 0, 0);
+                double2 gp;
+                __builtin_memcpy(&gp, &vp, sizeof gp);
+                const unsigned long long hit = __ballot(gp.x >= m_star);
+                if (!hit) { found = false; break; }    // (a table that is not monotone: no run)
+                const int L = __ffsll((long long)hit) - 1;
+                const int nlo = lo + L * stride;
+                hi = min(nlo + stride, hi);
+                lo = nlo;
+            }
+            if (!found) break;
+            const int aligned = first + ((lo - first + 63) & ~63);
+            if (aligned + 128 > run_end) break;        // not worth a loop of its own (nor are the sparser ones below)
+            seg_begin[sidx] = aligned;
+            seg_end[sidx] = run_end;
+            seg_j[sidx] = j;
+            n_seg = sidx + 1;
+            search_hi = lo + 1;
+            run_end = first + ((lo - first) & ~63);
         }
     }
+    const bool top_phase = n_seg > 0;
+    // Y / sqrt(2) = g_p |B| / (sqrt(2) f) = cYs |B|; sqrt(x) = x rsqrt(x) to 0.6 ulp in 8 instructions (the library's: ~25)
+    const double cYs = top_phase ? uniform(hcY2 * rsqrt_cubic(hcY2)) : 0.0;
     double accm = 0.0;                                 // sum of mu' * weight
     unsigned long long viol = 0;
     double2 g0 = grid_at(first);
@@ -1029,49 +1046,53 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     cur.j = 0;
     cur.above = 0.0;
     if (HINT) cur = cursor_at(first + lane < end ? g0.x : uniform(g0.x), span, a0v, kj, nodes_v, hint_v);
-    // two wave-iterations per trip so that the prefetch registers swap roles without moves
-    for (; first + 128 <= split; first += 128) {
-        const double2 g1 = grid_at(first + 64);
-        if (!CHECK) {
-            accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
-            g0 = grid_at(first + 128);
-            accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
-        } else {
-            unsigned long long viol2 = 0;
-            const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
-            const double2 g2 = grid_at(first + 128);
-            const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, cur);
-            if (viol) {                                // keep the points in front of the first one that fails
+    // whole wave-iterations [first, stop) with the indexed steps, two per trip so that the prefetch registers swap
+    // roles without moves
+    auto run_indexed = [&](int stop) {
+        for (; first + 128 <= stop; first += 128) {
+            const double2 g1 = grid_at(first + 64);
+            if (!CHECK) {
+                accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+                g0 = grid_at(first + 128);
+                accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+            } else {
+                unsigned long long viol2 = 0;
+                const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+                const double2 g2 = grid_at(first + 128);
+                const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, cur);
+                if (viol) {                            // keep the points in front of the first one that fails
+                    const int L = __ffsll((long long)viol) - 1;
+                    if (lane < L) accm = a1;
+                    first += L;
+                    return;
+                }
+                if (viol2) {
+                    const int L = __ffsll((long long)viol2) - 1;
+                    accm = lane < L ? a2 : a1;
+                    first += 64 + L;
+                    viol = viol2;
+                    return;
+                }
+                accm = a2;
+                g0 = g2;
+            }
+        }
+        if (first + 64 <= stop) {                      // odd whole wave-iteration left over
+            const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+            if (!(CHECK && viol)) {
+                accm = a1;
+                first += 64;
+                g0 = grid_at(first);
+            } else {
                 const int L = __ffsll((long long)viol) - 1;
                 if (lane < L) accm = a1;
                 first += L;
-                break;
             }
-            if (viol2) {
-                const int L = __ffsll((long long)viol2) - 1;
-                accm = lane < L ? a2 : a1;
-                first += 64 + L;
-                viol = viol2;
-                break;
-            }
-            accm = a2;
-            g0 = g2;
         }
-    }
-    if (!(CHECK && viol) && first + 64 <= split) {     // odd whole wave-iteration left over
-        const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
-        if (!(CHECK && viol)) {
-            accm = a1;
-            first += 64;
-            g0 = grid_at(first);
-        } else {
-            const int L = __ffsll((long long)viol) - 1;
-            if (lane < L) accm = a1;
-            first += L;
-        }
-    }
-    if (TOP && top_phase && !(CHECK && viol)) {        // the same two loops over the top segment
-        for (; first + 128 <= whole_end; first += 128) {
+    };
+    // ... and with the node of one segment held in registers
+    auto run_top = [&](int stop) {
+        for (; first + 128 <= stop; first += 128) {
             const double2 g1 = grid_at(first + 64);
             if (!CHECK) {
                 accm = lean_step_top<MODE, false, POLY>(g0, top, cX, hcY2, accm, wc, viol);
@@ -1086,20 +1107,20 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
                     const int L = __ffsll((long long)viol) - 1;
                     if (lane < L) accm = a1;
                     first += L;
-                    break;
+                    return;
                 }
                 if (viol2) {
                     const int L = __ffsll((long long)viol2) - 1;
                     accm = lane < L ? a2 : a1;
                     first += 64 + L;
                     viol = viol2;
-                    break;
+                    return;
                 }
                 accm = a2;
                 g0 = g2;
             }
         }
-        if (!(CHECK && viol) && first + 64 <= whole_end) {
+        if (first + 64 <= stop) {
             const double a1 = lean_step_top<MODE, CHECK, POLY>(g0, top, cX, hcY2, accm, wc, viol);
             if (!(CHECK && viol)) {
                 accm = a1;
@@ -1111,7 +1132,22 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
                 first += L;
             }
         }
+    };
+    if (TOP) {
+        // (one copy of the two loops: the run's bounds are picked with scalar selects, not by unrolling)
+#pragma unroll 1
+        for (int sidx = n_seg - 1; sidx >= 0 && !(CHECK && viol); --sidx) {
+            const int begin_s = sidx == 0 ? seg_begin[0] : (sidx == 1 ? seg_begin[1] : seg_begin[2]);
+            const int end_s = sidx == 0 ? seg_end[0] : (sidx == 1 ? seg_end[1] : seg_end[2]);
+            const int j_s = sidx == 0 ? seg_j[0] : (sidx == 1 ? seg_j[1] : seg_j[2]);
+            run_indexed(begin_s);
+            if (!(CHECK && viol)) {
+                top = top_segment(nodes_v, j_s, span, cYs);
+                run_top(end_s);
+            }
+        }
     }
+    if (!top_phase && !(CHECK && viol)) run_indexed(whole_end);
     if (!(CHECK && viol) && first < end) {             // partial wave-iteration: at most 64 points left
         const int idx = first + lane;
         const bool is_last = idx == last_special;
@@ -2201,6 +2237,13 @@ hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_by
     return hipGetLastError();
 }
 
+hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
+    constexpr int THREADS = PRHF_BLOCK_THREADS;
+    if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL((vfo_shortx_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
 #include "prhf_snell.inc"
 
 // Resident workgroups per CU the runtime predicts for the fused kernel (diagnostics).
@@ -2219,6 +2262,7 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
                              reinterpret_cast<const void*>(&vfo_short_kernel<THREADS>),
+                             reinterpret_cast<const void*>(&vfo_shortx_kernel<THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);

@@ -64,6 +64,24 @@ def gather_rows(local, n_total, group=None, force=False):
     return torch.cat([buf[r * biggest: r * biggest + counts[r]] for r in range(world)], dim=0)
 
 
+def gather_scalars(values, device="cpu", group=None):
+    """Every rank's small vector of float64 statistics (kernel time, gather time ...) as a ``(world, n)`` NumPy
+    array on every rank; ``(1, n)`` without a process group.  One flat ``all_gather_into_tensor`` (the flat form is
+    the one gloo and RCCL both take)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    mine = torch.as_tensor(np.asarray(values, dtype=np.float64).ravel())
+    if not dist.is_initialized():
+        return mine.numpy().reshape(1, -1).copy()
+    world = dist.get_world_size(group)
+    mine = mine.to(device)
+    every = torch.empty(world * mine.numel(), dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(every, mine, group=group)
+    return every.cpu().numpy().reshape(world, mine.numel())
+
+
 def shard_segments(segments, world_size, rank):
     """Cost-balanced cut of a mixed work list (BASELINE config 5).
 

@@ -131,3 +131,52 @@ def test_gather_mixed_single_process():
     local = torch.arange(rows.size * 3, dtype=torch.float64).reshape(rows.size, 3)
     full = pdist.gather_mixed(local, MIXED, 14)
     assert torch.isnan(full[8]).all() and torch.equal(full[torch.as_tensor(rows)], local)
+
+
+def _stats_worker(rank, world, port, result_path):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        every = pdist.gather_scalars([10.0 + rank, 0.5 * (rank + 1)])        # what bench.py sends: kernel ms, gather ms
+        # the one-rank short cut and its `force`d collective on a group of two: both go through the collective here
+        local = torch.full((3, 2), float(rank), dtype=torch.float64)
+        forced = pdist.gather_rows(local, 6, force=True)
+        if rank == 0:
+            np.savez(result_path, every=every, forced=forced.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_statistics_gather(tmp_path):
+    """bench.py's per-rank statistics (kernel_ms_per_rank, gather_ms) at N > 1: the flat all-gather both backends take."""
+    path = str(tmp_path / "stats.npz")
+    mp.spawn(_stats_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    assert np.array_equal(got["every"], np.array([[10.0, 0.5], [11.0, 1.0]]))
+    assert np.array_equal(got["forced"], np.repeat([[0.0, 0.0], [1.0, 1.0]], 3, axis=0))
+    assert np.array_equal(pdist.gather_scalars([1.0, 2.0, 3.0]), np.array([[1.0, 2.0, 3.0]]))      # no process group
+
+
+def _one_rank_worker(rank, world, port, result_path):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        local = torch.arange(12, dtype=torch.float64).reshape(4, 3)
+        plain, forced = pdist.gather_rows(local, 4), pdist.gather_rows(local, 4, force=True)
+        rows, segs = pdist.shard_segments(MIXED, 1, 0)
+        mixed = torch.arange(rows.size * 2, dtype=torch.float64).reshape(rows.size, 2)
+        full = pdist.gather_mixed(mixed, MIXED, 14, force=True)
+        ok = ((plain is local) and (forced is not local) and torch.equal(forced, local)
+              and torch.equal(full[torch.as_tensor(rows)], mixed) and bool(torch.isnan(full[8]).all()))
+        np.save(result_path, np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_forced_through_the_collective(tmp_path):
+    """`force=True`: a group of ONE rank still goes through all_gather_into_tensor (the N > 1 code path on one device)."""
+    path = str(tmp_path / "one.npy")
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), path), nprocs=1, join=True)
+    assert bool(np.load(path)[0])

@@ -502,7 +502,15 @@ def test_more_frequencies_than_the_candidate_list_holds(lib):
     g = load_golden("g5_chapman64.npz")
     freq = np.linspace(0.3, 17.0, 1100)
     long_ = lib.vertical_forward_operator(freq, g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
+    # (1000 frequencies of a 300-point grid go to the X-mode short-grid kernel, 1100 to the general one: another
+    #  summation order, ~1e-15 apart; inside the general kernel the list changes nothing, bit for bit)
     head = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
+    assert_x_mode(long_[:, :1000], head, tol=1e-12)
+    lib.set_option("shortx_kernel", 0)
+    try:
+        head = lib.vertical_forward_operator(freq[:1000], g["den"][:8], g["bmag"][:8], g["bpsi"][:8], g["alt"], "X", 300)
+    finally:
+        lib.set_option("shortx_kernel", 1)
     assert np.array_equal(long_[:, :1000], head, equal_nan=True)
     # O mode, n_points = 200: 1000 frequencies go to the short-grid kernel, 1100 (more than its list holds) to the
     # general one - which chooses between its two formulations per wave-iteration, not per point: ~1e-10 apart
@@ -519,3 +527,34 @@ def test_more_frequencies_than_the_candidate_list_holds(lib):
         lib.set_option("short_kernel", 1)
     assert np.array_equal(lo[:, :1000], ho_general, equal_nan=True)
     assert 0.3 < np.isfinite(long_).mean() < 0.8
+
+
+def test_short_grid_kernels_every_shape(lib):
+    """vfo_short_kernel (O mode) and vfo_shortx_kernel (X mode) on grid sizes around their wave-iteration boundaries
+    (16 points per pair and wave-iteration; one full trip = 32): X mode against the C oracle; O mode against the
+    general kernel (which chooses its arithmetic per wave-iteration, not per point: ~1e-10 apart) and, for three
+    sizes, against the NumPy oracle under the parity rule."""
+    from oracle import vfo_c, vfo_numpy
+    g = load_golden("g5_chapman64.npz")
+    args = (g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"])           # 64 x 174 pairs: a long launch
+    for n in (2, 3, 15, 16, 17, 31, 32, 33, 48, 64, 65, 129, 200, 511, 1000, 1024):
+        got_x = lib.vertical_forward_operator(*args, "X", n)
+        if vfo_c.available():
+            assert_x_mode(got_x, vfo_c.virtual_heights_batch(*args, "X", n), tol=1e-9)
+        got_o = lib.vertical_forward_operator(*args, "O", n)
+        lib.set_option("short_kernel", 0)
+        lib.set_option("shortx_kernel", 0)
+        try:
+            gen_o = lib.vertical_forward_operator(*args, "O", n)
+            gen_x = lib.vertical_forward_operator(*args, "X", n)
+        finally:
+            lib.set_option("short_kernel", 1)
+            lib.set_option("shortx_kernel", 1)
+        assert_masks(got_o, gen_o)
+        err, ok = rel_err(got_o, gen_o)
+        assert err.max(initial=0.0) <= 2e-7, (n, err.max())
+        assert_x_mode(got_x, gen_x, tol=1e-9)
+        if n in (2, 17, 200):
+            with np.errstate(all="ignore"):
+                want = vfo_numpy.virtual_heights_batch(*args, "O", n)
+            assert_o_mode(got_o, want, oracle_noise(*args, "O", n, runs=12), min_within=0.99)

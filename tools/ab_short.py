@@ -26,6 +26,15 @@ def child(tag, n_prof):
                 ms.append(ctx.last_kernel_ms())
         res[f"config3_n{n_points}_ms"] = float(np.median(ms))
         np.save(os.path.join(ROOT, "gpurun_out", f"ab_short_{tag}_n{n_points}.npy"), out.cpu().numpy())
+    for mode, n_points, rows in (("X", 200, 10000), ("X", 500, 10000), ("X", 1000, 10000), ("X", 2000, 4000)):
+        tx = [t[0]] + [x[:rows] for x in t[1:4]] + [t[4]]
+        ms = []
+        for r in range(8):
+            out = library.vertical_forward_operator(*tx, mode, n_points, sync=True)
+            if r >= 2:
+                ms.append(ctx.last_kernel_ms())
+        res[f"{mode}{n_points}_{rows}x174_ms"] = float(np.median(ms))
+        np.save(os.path.join(ROOT, "gpurun_out", f"ab_short_{tag}_x{n_points}.npy"), out.cpu().numpy())
     from bench import CONFIG5_SEGMENTS
     rows, segs = pdist.shard_segments(CONFIG5_SEGMENTS, 8, 0)
     alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=rows)
@@ -46,9 +55,9 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
 n_prof = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 for tag, knob, qfix, conc in (("general", "0", "0", "1"), ("short", "1", "0", "1"), ("tinyq", "1", "40", "1"),
                               ("sequential", "1", "0", "0")):
-    env = dict(os.environ, AB_OPTIONS=f"short_kernel={knob},short_queue={qfix},short_concurrent={conc}")
+    env = dict(os.environ, AB_OPTIONS=f"short_kernel={knob},shortx_kernel={knob},short_queue={qfix},short_concurrent={conc}")
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", tag, str(n_prof)], env=env, check=True)
-for key in ("n200", "n500", "n1000", "c5"):
+for key in ("n200", "n500", "n1000", "x200", "x2000", "c5"):
     b = np.load(os.path.join(ROOT, "gpurun_out", f"ab_short_short_{key}.npy"))
     t = np.load(os.path.join(ROOT, "gpurun_out", f"ab_short_tinyq_{key}.npy"))
     print(json.dumps({"compare": key, "queue of 40 entries bit-identical to the default": bool(np.array_equal(b, t, equal_nan=True))}))

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Condense a tools/profile.sh output directory into profiles/<tag>.md (+ hbm_traffic.json).
 
-    python tools/summarize_profile.py gpurun_out/prof_r01_v2 r01_v2 [workload-key] [kernel-substring] [description]
+    python tools/summarize_profile.py gpurun_out/prof_r01_v2 r01_v2 [workload-key] [kernel-substring[,substring...]] [description]
+
+Several substrings (a launch made of several kernels - the mixed work list runs a short-grid and a general kernel
+side by side): counters are averaged per exact kernel name and then added up; the launch time is then the
+HIP-event time bench.py reports (`kernel_ms` in the traced run's JSON line), not a single kernel's duration.
 
 Kernel time comes from `rocprofv3 --kernel-trace --stats`; counters from separate `--pmc`
 passes.  HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB
@@ -41,37 +45,58 @@ def main():
              f"Source: `tools/profile.sh {tag}` on one MI355X, workload `{key}` ({desc}); counters are those of the "
              f"dispatches whose kernel name contains `{kernel}`.", ""]
 
+    wanted = [k for k in kernel.split(",") if k]
+    selected = lambda name: any(k in name for k in wanted) and "finalize" not in name      # noqa: E731
     stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     avg_ns = None
+    per_kernel_ns = {}
     if stats:
         lines += ["## Kernel trace (`--kernel-trace --stats`)", "",
                   "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
         for r in csv.DictReader(open(stats[0])):
             lines.append(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | "
                          f"{float(r['MinNs'])/1e6:.3f} | {float(r['MaxNs'])/1e6:.3f} | {float(r['Percentage']):.3f} |")
-            if kernel in r["Name"]:
-                avg_ns = float(r["AverageNs"])
+            if selected(r["Name"]):
+                per_kernel_ns[r["Name"]] = float(r["AverageNs"])
         lines.append("")
+    big = {k: v for k, v in per_kernel_ns.items() if v > 0.02 * max(per_kernel_ns.values(), default=0.0)}
+    if len(big) == 1:
+        avg_ns = next(iter(big.values()))
+    elif len(big) > 1:
+        # several kernels side by side: the launch time is the HIP-event time of the traced bench run
+        log = os.path.join(src, "trace.log")
+        if os.path.exists(log):
+            for ln in open(log):
+                if ln.startswith("{") and '"kernel_ms"' in ln:
+                    avg_ns = json.loads(ln)["kernel_ms"] * 1e6
+        lines += [f"Launch = {len(big)} kernels side by side ({', '.join('`' + k.split('(')[0] + '`' for k in big)}): rates below use "
+                  f"the HIP-event time of the traced run, {avg_ns / 1e6:.3f} ms per launch.", ""] if avg_ns else []
     trace = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")))
     if trace:
+        seen = set()
         for r in csv.DictReader(open(trace[0])):
-            if kernel in r["Kernel_Name"]:
-                lines += [f"Dispatch: grid {r['Grid_Size_X']} threads, workgroup {r['Workgroup_Size_X']}, "
+            if selected(r["Kernel_Name"]) and r["Kernel_Name"] not in seen and r["Kernel_Name"] in big:
+                seen.add(r["Kernel_Name"])
+                lines += [f"`{r['Kernel_Name'].split('(')[0]}`: "] + [f"Dispatch: grid {r['Grid_Size_X']} threads, workgroup {r['Workgroup_Size_X']}, "
                           f"LDS {r['LDS_Block_Size']} B/workgroup, VGPR {r['VGPR_Count']}, "
                           f"SGPR {r['SGPR_Count']}, scratch {r['Scratch_Size']} B.", ""]
-                break
 
-    counters = collections.defaultdict(list)
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))      # counter -> exact kernel name -> values
     for path in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(path)):
-            if kernel in r["Kernel_Name"]:
-                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+            if selected(r["Kernel_Name"]):
+                counters[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    # mean per dispatch of each kernel, added up over the kernels of the launch
+    mean = {c: sum(sum(v) / len(v) for v in by.values()) for c, by in counters.items()}
     if mean:
-        lines += ["## Counters (separate `--pmc` passes, mean per dispatch of the selected kernel)", "",
-                  "| counter | value |", "|---|---|"]
+        names = sorted({n for by in counters.values() for n in by})
+        lines += ["## Counters (separate `--pmc` passes, mean per dispatch" +
+                  (", added up over the launch's kernels)" if len(names) > 1 else " of the selected kernel)"), "",
+                  "| counter | " + " | ".join("`" + n.split("(")[0].replace("void prhf::", "") + "`" for n in names) +
+                  (" | launch |" if len(names) > 1 else " |"), "|---|" + "---|" * (len(names) + (1 if len(names) > 1 else 0))]
         for k in sorted(mean):
-            lines.append(f"| {k} | {mean[k]:.6g} |")
+            cells = [f"{sum(counters[k][n]) / len(counters[k][n]):.6g}" if n in counters[k] else "-" for n in names]
+            lines.append(f"| {k} | " + " | ".join(cells) + (f" | {mean[k]:.6g} |" if len(names) > 1 else " |"))
         lines.append("")
 
     derived = []

@@ -11,15 +11,15 @@ cd /tmp
 i=0
 while read -r ARGS; do
   i=$((i+1))
-  B="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-profile $ARGS"
+  B="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-profile --no-legs $ARGS"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/w$i/trace" -- $B > "$OUT/w$i.json" 2> "$OUT/w$i.trace.log"
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/w$i/pmc" -- $B > /dev/null 2> "$OUT/w$i.pmc.log"
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/w$i/pmc" -- $B > /dev/null 2> "$OUT/w$i.pmc.log"
   echo "$ARGS" > "$OUT/w$i.args"
 done <<'LIST'
---profiles 7500 --freqs 512 --n-points 2000 --mode X
---profiles 5000 --freqs 512 --n-points 2000 --mode O
---profiles 2500 --freqs 512 --n-points 20000 --mode X
---profiles 10000 --freqs 512 --n-points 200 --mode O
+--profiles 10000 --freqs 174 --n-points 1000 --mode X
+--profiles 10000 --freqs 174 --n-points 1000 --mode X --option shortx_kernel=0
+--profiles 10000 --freqs 174 --n-points 200 --mode X
+--profiles 10000 --freqs 174 --n-points 200 --mode X --option shortx_kernel=0
 LIST
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, os, collections
@@ -32,7 +32,7 @@ for d in sorted(glob.glob(os.path.join(out, "w*.args"))):
     acc = collections.defaultdict(list)
     for p in glob.glob(w + "/pmc/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(p)):
-            if "vfo_" in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"]:
+            if "vfo_" in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"] and float(r["Counter_Value"]) > 0:
                 acc[(r["Kernel_Name"][:30], r["Counter_Name"])].append(float(r["Counter_Value"]))
     ks = collections.defaultdict(dict)
     for (k, c), v in acc.items():
@@ -42,5 +42,6 @@ for d in sorted(glob.glob(os.path.join(out, "w*.args"))):
     print(json.dumps({"args": args, "kernel_ms": b.get("kernel_ms"), "pairs": pairs, "reflecting": refl,
                       "kernels": {k: {"valu": v.get("SQ_INSTS_VALU"), "valu_per_reflecting_pair": (v.get("SQ_INSTS_VALU", 0) / (pairs * refl)) if pairs and refl else None,
                                       "valu_busy": (v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024) / (v.get("GRBM_GUI_ACTIVE", 1) / 8),
-                                      "salu": v.get("SQ_INSTS_SALU")} for k, v in ks.items()}}))
+                                      "salu": v.get("SQ_INSTS_SALU"), "lds_insts": v.get("SQ_INSTS_LDS"), "lds_active": v.get("SQ_LDS_IDX_ACTIVE"),
+                                      "lds_conflict": v.get("SQ_LDS_BANK_CONFLICT")} for k, v in ks.items()}}))
 PY
