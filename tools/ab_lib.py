@@ -25,6 +25,9 @@ def child():
     f174, f256, f512 = synth.sounder_frequencies(1), synth.sounder_frequencies(4), synth.sounder_frequencies(5)
     alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
     run("config3 O/200 10000x174", f174, alt, den, bmag, bpsi, "O", 200, reps=10)
+    run("O/500 10000x174", f174, alt, den, bmag, bpsi, "O", 500)
+    run("X/200 10000x174", f174, alt, den, bmag, bpsi, "X", 200, reps=10)
+    run("X/1000 10000x174", f174, alt, den, bmag, bpsi, "X", 1000)
     run("O/2000 5000x512", f512, alt, den[:5000], bmag[:5000], bpsi[:5000], "O", 2000)
     run("X/2000 7500x512", f512, alt, den[:7500], bmag[:7500], bpsi[:7500], "X", 2000)
     run("O/20000 1000x174", f174, alt, den[:1000], bmag[:1000], bpsi[:1000], "O", 20000, reps=3)
