@@ -50,9 +50,10 @@ extern "C" {
 /* flags of prhf_vfo_batch_f64 / prhf_vfo_worklist_f64 */
 #define PRHF_FLAG_DEVICE_PTRS 0x1u  /* every array pointer (inputs, multiplier, output) is device memory */
 #define PRHF_FLAG_ASYNC       0x2u  /* device pointers only: enqueue and return; data errors surface at prhf_sync */
-#define PRHF_FLAG_GRID_STABLE 0x4u  /* device pointers only: the multiplier array at this address keeps its contents
-                                     * for as long as the context lives, so the table the library derives from it
-                                     * (grid steps, one small kernel) is built once per (address, length) and reused */
+#define PRHF_FLAG_GRID_STABLE 0x4u  /* the multiplier array at this address (device or host) keeps its contents for as
+                                     * long as the context lives, so the table the library derives from it (grid steps,
+                                     * one small kernel) - and, for a host array, its device copy - is made once per
+                                     * (address, length) and reused (at most 16 host grids are remembered) */
 #define PRHF_FLAG_SHARED_FIELD 0x8u /* bmag and bpsi are ONE row of n_alt values each, shared by every profile (a fit's
                                      * candidates differ in their density only, library.py:589-591): a third of the
                                      * bytes to upload and to read */

@@ -158,6 +158,18 @@ struct prhf_ctx {
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
+    // PRHF_FLAG_GRID_STABLE with HOST buffers: the stretched grid at a host address that keeps its contents is
+    // uploaded, and its pair table built, once (a 20 000-point grid is 160 KB: more than the rest of a
+    // single-profile call's inputs together)
+    struct HostGrid {
+        const double* host = nullptr;
+        int64_t len = 0;
+        DevBuf mult, pairs;
+        bool pairs_ready = false;
+    };
+    static constexpr int kHostGrids = 16;
+    HostGrid host_grid[kHostGrids];
+    int n_host_grids = 0;
     unsigned* d_status = nullptr;   // device words [1..5]: block queues of persistent launches (general, short-grid O and its
                                     // follow-up, short-grid X and its follow-up); [0] unused
     unsigned* h_status = nullptr;   // PRHF_STATUS_WORDS words of pinned host memory mapped into the device: word b = status
@@ -272,13 +284,16 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         return fail(PRHF_EINVAL, "unknown flag bits");
     const bool dev = (flags & PRHF_FLAG_DEVICE_PTRS) != 0;
     const bool shared_field = (flags & PRHF_FLAG_SHARED_FIELD) != 0;
-    if ((flags & (PRHF_FLAG_ASYNC | PRHF_FLAG_GRID_STABLE)) && !dev)
-        return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC and PRHF_FLAG_GRID_STABLE need device pointers");
+    if ((flags & PRHF_FLAG_ASYNC) && !dev) return fail(PRHF_EINVAL, "PRHF_FLAG_ASYNC needs device pointers");
     // (A sounder frequency that is not a positive finite number gives a NaN column, host and device buffers alike:
     //  freq_table_kernel / pair_freq.  The reference returns NaN for 0 and NaN, and something meaningless for f < 0.)
     // The stretched grid must not decrease (smooth_nonuniform_grid never does): the top-segment search of the main
     // loop relies on it.  Checked here for host buffers; device-resident grids are the caller's.
-    if (!dev)
+    bool grid_known = false;                   // (a stable host grid that is cached already was checked when it was uploaded)
+    if (!dev && (flags & PRHF_FLAG_GRID_STABLE))
+        for (int g = 0; g < c->n_host_grids; ++g)
+            grid_known = grid_known || (c->host_grid[g].host == mult && c->host_grid[g].len == mult_len);
+    if (!dev && !grid_known)
         for (int32_t g = 0; g < n_segs; ++g)
             if (segs[g].mult_offset >= 0 && segs[g].n_points >= 1 && segs[g].mult_offset + segs[g].n_points <= mult_len)
                 for (int64_t i = segs[g].mult_offset + 1; i < segs[g].mult_offset + segs[g].n_points; ++i)
@@ -426,6 +441,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     const size_t row_bytes = (size_t)n_alt * 8;
     double* d_out = nullptr;
     bool out_direct = false;
+    prhf_ctx::HostGrid* grid = nullptr;        // host buffers with PRHF_FLAG_GRID_STABLE: the cached device copy of the grid
     const size_t out_elems = (size_t)out_rows * (size_t)n_freq;
     if (dev) {
         a.freq = freq; a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.mult = mult;
@@ -437,8 +453,24 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         const size_t n_alt_rows = alt_stride ? (size_t)n_prof : 1;
         const size_t n_field_rows = shared_field ? 1 : (size_t)n_prof;
         const size_t post_elems = post ? (size_t)n_freq + out_elems + (size_t)n_prof : 0;
+        // a stable host grid lives in a device buffer of its own, uploaded on first sight
+        if (flags & PRHF_FLAG_GRID_STABLE) {
+            for (int g = 0; g < c->n_host_grids; ++g)
+                if (c->host_grid[g].host == mult && c->host_grid[g].len == mult_len) grid = &c->host_grid[g];
+            if (!grid && c->n_host_grids < prhf_ctx::kHostGrids) {
+                prhf_ctx::HostGrid& g = c->host_grid[c->n_host_grids];
+                if ((rc = ensure(c, g.mult, (size_t)mult_len * 8)) != PRHF_OK) return rc;
+                HIP_TRY(hipMemcpyAsync(g.mult.p, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
+                g.host = mult;
+                g.len = mult_len;
+                g.pairs_ready = false;
+                grid = &g;
+                ++c->n_host_grids;
+            }
+        }
+        const size_t mult_arena = grid ? 0 : (size_t)mult_len;
         const size_t elems = (size_t)n_freq + ((size_t)n_prof + 2 * n_field_rows) * n_alt + n_alt_rows * n_alt +
-                             (size_t)mult_len + out_elems + post_elems;
+                             mult_arena + out_elems + post_elems;
         if ((rc = ensure(c, c->arena, elems * 8)) != PRHF_OK) return rc;
         double* base = static_cast<double*>(c->arena.p);
         double* d_freq = base;
@@ -447,7 +479,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         double* d_bpsi = d_bmag + n_field_rows * n_alt;
         double* d_alt = d_bpsi + n_field_rows * n_alt;
         double* d_mult = d_alt + n_alt_rows * n_alt;
-        d_out = d_mult + mult_len;
+        d_out = d_mult + mult_arena;
         const size_t in_elems = (size_t)(d_out - base);
         if (in_elems * 8 <= kPackBytes && c->h_pack) {
             // A small call (the reference's usual one: a single profile): six separate uploads from pageable
@@ -466,11 +498,11 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 if (alt_stride) std::memcpy(h + (d_alt - base) + (size_t)p * n_alt, alt + (size_t)p * alt_stride, row_bytes);
             }
             if (!alt_stride) std::memcpy(h + (d_alt - base), alt, row_bytes);
-            std::memcpy(h + (d_mult - base), mult, (size_t)mult_len * 8);
+            if (!grid) std::memcpy(h + (d_mult - base), mult, (size_t)mult_len * 8);
             HIP_TRY(hipMemcpyAsync(base, h, in_elems * 8, hipMemcpyHostToDevice, c->stream));
         } else {
             HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
+            if (!grid) HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
             if (n_prof > 0) {
                 HIP_TRY(hipMemcpy2DAsync(d_den, row_bytes, den, (size_t)prof_stride * 8, row_bytes, (size_t)n_prof,
                                          hipMemcpyHostToDevice, c->stream));
@@ -487,7 +519,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 HIP_TRY(hipMemcpyAsync(d_alt, alt, row_bytes, hipMemcpyHostToDevice, c->stream));
             }
         }
-        a.freq = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.mult = d_mult;
+        a.freq = d_freq; a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt;
+        a.mult = grid ? static_cast<const double*>(grid->mult.p) : d_mult;
         a.out = d_out;
         // rows that no segment covers must come back as NaN, not as whatever the arena held (all-ones bytes = NaN)
         long long covered = 0;
@@ -525,9 +558,19 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
+    if (want_pairs && grid) {
+        if (!grid->pairs_ready) {
+            if ((rc = ensure(c, grid->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
+            HIP_TRY(prhf::launch_grid_pairs(a.mult, mult_len, static_cast<double*>(grid->pairs.p), c->stream));
+            grid->pairs_ready = true;
+        }
+        a.pairs = static_cast<const double*>(grid->pairs.p);
+    }
     if (want_pairs) {
-        const bool stable = (flags & PRHF_FLAG_GRID_STABLE) != 0;
-        if (!(stable && c->pairs.p && c->pairs_src == a.mult && c->pairs_len == mult_len)) {
+        const bool stable = dev && (flags & PRHF_FLAG_GRID_STABLE) != 0;
+        if (grid) {
+            // (table cached with the grid, above)
+        } else if (!(stable && c->pairs.p && c->pairs_src == a.mult && c->pairs_len == mult_len)) {
             c->pairs_src = nullptr;
             if ((rc = ensure(c, c->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
             HIP_TRY(prhf::launch_grid_pairs(a.mult, mult_len, static_cast<double*>(c->pairs.p), c->stream));
@@ -536,7 +579,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 c->pairs_len = mult_len;
             }
         }
-        a.pairs = static_cast<const double*>(c->pairs.p);
+        if (!grid) a.pairs = static_cast<const double*>(c->pairs.p);
         // per-frequency scalars: long launches read them from a table instead of dividing once per pair (a short
         // launch - one profile - is latency bound: it does without the extra kernel)
         if (n_prof * n_freq >= 4096) {
@@ -770,6 +813,10 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->levels.p) (void)hipFree(c->levels.p);
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
+    for (int g = 0; g < c->n_host_grids; ++g) {
+        if (c->host_grid[g].mult.p) (void)hipFree(c->host_grid[g].mult.p);
+        if (c->host_grid[g].pairs.p) (void)hipFree(c->host_grid[g].pairs.p);
+    }
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_pack) (void)hipHostFree(c->h_pack);

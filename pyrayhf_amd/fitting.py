@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from .library import _mode_code, _multiplier, _as_rows, _is_torch, _device_grid, MATH_AUTO
+from .library import _mode_code, _multiplier, _as_rows, _is_torch, _device_grid, _grid_flag, MATH_AUTO
 
 __all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace", "brute_grid", "minimize_parameters"]
 
@@ -81,7 +81,7 @@ def residual_VH_batch(freq, vh_obs, den, bmag, bpsi, alt, mode='O', n_points=200
                                        a.ctypes.data, n_prof, n_alt, n_alt, 0, mult.ctypes.data, int(n_points), code,
                                        obs.ctypes.data, vh.ctypes.data if return_vh else None,
                                        residual.ctypes.data, cost.ctypes.data,
-                                       _native.FLAG_SHARED_FIELD if shared else 0))
+                                       (_native.FLAG_SHARED_FIELD if shared else 0) | _grid_flag(mult, n_points)))
     out = (residual, cost) if return_cost else (residual,)
     if return_vh:
         out = out + (vh,)

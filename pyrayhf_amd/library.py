@@ -177,10 +177,15 @@ def _multiplier(n_points):
     if m is None:
         with np.errstate(all="ignore"):
             m = np.ascontiguousarray(smooth_nonuniform_grid(0, 1, n, 10.0), dtype=np.float64)
-        if len(_mult_cache) > 32:
-            _mult_cache.clear()
-        _mult_cache[n] = m
+        m.flags.writeable = False
+        if len(_mult_cache) < 12:            # entries are never evicted: the library caches their device copies by address
+            _mult_cache[n] = m
     return m
+
+
+def _grid_flag(m, n_points):
+    """PRHF_FLAG_GRID_STABLE for a host grid that is one of the cached (never freed, never written) ones."""
+    return _native.FLAG_GRID_STABLE if _mult_cache.get(int(n_points)) is m else 0
 
 
 def _is_torch(x):
@@ -224,7 +229,7 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     ctx.set_math(_default_math(mode_code, math))
     rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
                        n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
-                       out.ctypes.data, _native.FLAG_SHARED_FIELD if shared else 0)
+                       out.ctypes.data, (_native.FLAG_SHARED_FIELD if shared else 0) | _grid_flag(mult, n_points))
     _native.raise_for(rc)
     return out[0] if single else out
 

@@ -455,14 +455,33 @@ def test_cached_device_grids_alternate_without_going_stale(lib):
         assert np.array_equal(lib.vertical_forward_operator(*h, "X", n), want[n], equal_nan=True), n
 
 
-def test_flag_validation_of_the_grid_stable_bit():
-    """PRHF_FLAG_GRID_STABLE only makes sense for device pointers."""
-    from pyrayhf_amd import _native
-    ctx = _native.context(0)
+def test_host_grid_marked_stable_is_uploaded_once_and_never_goes_stale():
+    """PRHF_FLAG_GRID_STABLE with host buffers (round 3): the grid at a host address is uploaded, and its table built,
+    once per (address, length).  A grid of the same length at ANOTHER address must not get the first one's copy, and
+    PRHF_FLAG_ASYNC still needs device pointers."""
+    from pyrayhf_amd import _native, library
+    g = load_golden("g5_chapman64.npz")
+    ctx = _native.host_context(0)
+    f, d, b, p, a = (np.ascontiguousarray(g[k], dtype=np.float64) for k in ("freq", "den", "bmag", "bpsi", "alt"))
+    n = 2000
+    m1 = np.ascontiguousarray(library.smooth_nonuniform_grid(0, 1, n, 10.0))
+    m2 = np.ascontiguousarray(np.linspace(0.0, 1.0, n))                     # another grid of the same length
+    out = {}
+    for tag, m, flag in (("a", m1, _native.FLAG_GRID_STABLE), ("b", m2, _native.FLAG_GRID_STABLE),
+                         ("a2", m1, _native.FLAG_GRID_STABLE), ("a_plain", m1, 0), ("b_plain", m2, 0)):
+        o = np.empty((64, f.size))
+        ctx.set_math(_native.MATH_AUTO)
+        _native.raise_for(ctx.vfo_batch(f.ctypes.data, f.size, d.ctypes.data, b.ctypes.data, p.ctypes.data, a.ctypes.data,
+                                        64, a.size, a.size, 0, m.ctypes.data, n, _native.MODE_X, o.ctypes.data, flag))
+        out[tag] = o
+    assert np.array_equal(out["a"], out["a_plain"], equal_nan=True) and np.array_equal(out["a2"], out["a"], equal_nan=True)
+    assert np.array_equal(out["b"], out["b_plain"], equal_nan=True)
+    assert not np.array_equal(out["a"], out["b"], equal_nan=True)
+    assert np.array_equal(out["a"], library.vertical_forward_operator(f, d, b, p, a, "X", n), equal_nan=True)
     one = np.ones(4)
-    out = np.empty(1)
+    o1 = np.empty(1)
     rc = ctx.vfo_batch(one.ctypes.data, 1, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data,
-                       1, 4, 4, 0, one.ctypes.data, 4, 0, out.ctypes.data, _native.FLAG_GRID_STABLE)
+                       1, 4, 4, 0, one.ctypes.data, 4, 0, o1.ctypes.data, _native.FLAG_ASYNC)
     assert rc == _native.EINVAL and "device pointers" in _native.last_error()
 
 
