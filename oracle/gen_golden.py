@@ -20,6 +20,7 @@ Fixtures:
   G7  edge cases
   G8/G9  stratified Snell's-law rays, flat and spherical Earth
   G10 the first 64 profiles of BASELINE config 3 (seed 20260003) x 174 freqs, O/200 + noise floors
+  G13 profiles of 2 600 / 3 096 levels (more than the kernel keeps in LDS) and NaN-padded densities
   G11 residual_VH (library.py:595-669) rows: the reference function itself, with model_VH replaced by
       a stand-in that builds the EDP without PyIRI and calls the reference's own operator
   G12 (made with the ORACLE, not the reference: it needs a hook inside find_mu_mup) "rounding noise" of
@@ -256,6 +257,7 @@ def main():
     gen_config3(lib)
     gen_residual(lib)
     gen_rounding_noise(lib)
+    gen_tall(lib)
     print("fixtures written to", OUT)
 
 
@@ -456,12 +458,55 @@ def gen_rounding_noise(lib):
     np.savez(os.path.join(OUT, "g12_rounding_noise.npz"), **g12)
 
 
+def gen_tall(lib):
+    """G13.  Profiles of more levels than the kernel keeps in LDS (the reference has no limit, library.py:371-375)
+    and densities padded with NaN (np.argmax returns the first NaN, :371: the padding acts as the peak).
+      tall_day   the Day example resampled to 0.2 km (3 096 levels), 174 freqs: O/200 with its noise floor, X/2000
+      tall_rag   a Chapman layer on 2 600 levels with irregular spacing (0.05 - 0.45 km), 96 freqs: O/200, X/500
+      nanpad     the Day example with den = NaN from level 300 up (above the peak at 258) and from level 200 up
+                 (below it: the layer is cut short), 174 freqs, O/200 and X/200"""
+    from pyrayhf_amd import synth
+    g = {}
+    d = load_example("Day")
+    freq = np.arange(0.1, 17.5, 0.1)
+    alt = np.arange(d["alt"][0], d["alt"][-1] + 1e-9, 0.2)
+    tall = {k: np.interp(alt, d["alt"], d[k]) for k in ("den", "bmag", "bpsi")}
+    g.update(tall_day_freq=freq, tall_day_alt=alt, tall_day_den=tall["den"], tall_day_bmag=tall["bmag"],
+             tall_day_bpsi=tall["bpsi"])
+    g["tall_day_O_200_vh"], g["tall_day_O_200_noise"] = noise_floor(lib, freq, tall["den"], tall["bmag"], tall["bpsi"],
+                                                                    alt, "O", 200, seed=1301)
+    g["tall_day_X_2000_vh"] = lib.vertical_forward_operator(freq, tall["den"], tall["bmag"], tall["bpsi"], alt, "X", 2000)
+    rng = np.random.default_rng(1302)
+    alt_r = 80.0 + np.concatenate(([0.0], np.cumsum(rng.uniform(0.05, 0.45, size=2599))))
+    a1, den1, bmag1, bpsi1 = synth.chapman_profiles(4, 1302, rows=slice(2, 3))
+    rag = {"den": np.interp(alt_r, a1, den1[0]), "bmag": np.interp(alt_r, a1, bmag1[0]),
+           "bpsi": np.interp(alt_r, a1, bpsi1[0])}
+    freq_r = np.linspace(0.6, 14.0, 96)
+    g.update(tall_rag_freq=freq_r, tall_rag_alt=alt_r, tall_rag_den=rag["den"], tall_rag_bmag=rag["bmag"],
+             tall_rag_bpsi=rag["bpsi"])
+    g["tall_rag_O_200_vh"], g["tall_rag_O_200_noise"] = noise_floor(lib, freq_r, rag["den"], rag["bmag"], rag["bpsi"],
+                                                                    alt_r, "O", 200, seed=1303)
+    g["tall_rag_X_500_vh"] = lib.vertical_forward_operator(freq_r, rag["den"], rag["bmag"], rag["bpsi"], alt_r, "X", 500)
+    g.update(nanpad_freq=freq, nanpad_alt=d["alt"], nanpad_bmag=d["bmag"], nanpad_bpsi=d["bpsi"])
+    for first in (300, 200):
+        den = d["den"].copy()
+        den[first:] = np.nan
+        g[f"nanpad_{first}_den"] = den
+        g[f"nanpad_{first}_O_200_vh"], g[f"nanpad_{first}_O_200_noise"] = noise_floor(
+            lib, freq, den, d["bmag"], d["bpsi"], d["alt"], "O", 200, seed=1304 + first)
+        g[f"nanpad_{first}_X_200_vh"] = lib.vertical_forward_operator(freq, den, d["bmag"], d["bpsi"], d["alt"], "X", 200)
+    np.savez(os.path.join(OUT, "g13_tall_nanpad.npz"), **g)
+    for k in sorted(g):
+        if k.endswith("_vh"):
+            print("G13", k, "finite", int(np.isfinite(g[k]).sum()), "of", g[k].size, flush=True)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
         np.seterr(all="ignore")
         ref = load_reference_library()
         for what in only:
-            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual, "g12": gen_rounding_noise}[what](ref)
+            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual, "g12": gen_rounding_noise, "g13": gen_tall}[what](ref)
     else:
         main()

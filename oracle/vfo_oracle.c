@@ -127,7 +127,8 @@ static int one_profile(const double* freq_mhz, int64_t n_freq, const double* den
     int64_t K = 0;                                   /* :371 first-occurrence argmax */
     double alt_min = alt[0];
     for (int64_t i = 0; i < n_alt; ++i) {
-        if (den[i] > den[K]) K = i;
+        /* np.argmax: a NaN outranks every number, the first one wins */
+        if (den[K] == den[K] && (den[i] != den[i] || den[i] > den[K])) K = i;
         if (alt[i] < alt_min) alt_min = alt[i];
     }
     if (K == 0) return -3;

@@ -82,6 +82,8 @@ const KnobName kKnobNames[] = {
     {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
+constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
+                                           // indices travel as uint16 in the hint table
 constexpr int kWavesPerBlock = PRHF_BLOCK_THREADS / 64;
 
 struct DevBuf {
@@ -156,6 +158,7 @@ struct prhf_ctx {
     DevBuf levels;    // level table of a grouped tracer launch
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
+    DevBuf tall;         // profiles of more than kMaxAlt levels: one slab of staged levels per resident workgroup
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
     // PRHF_FLAG_GRID_STABLE with HOST buffers: the stretched grid at a host address that keeps its contents is
@@ -256,7 +259,7 @@ int status_to_code(unsigned bits) {
     if (bits & PRHF_STATUS_PEAK0)
         return fail(PRHF_EPEAK0, "density peak at index 0: no bottomside levels below the peak");
     if (bits & PRHF_STATUS_NANINPUT)
-        return fail(PRHF_EINVAL, "NaN in a profile (den or alt anywhere in the column, bmag or bpsi below the density peak)");
+        return fail(PRHF_EINVAL, "NaN in a profile (alt anywhere in the column, bmag or bpsi below the density peak)");
     if (bits & PRHF_STATUS_NEGDEN) return fail(PRHF_ENEGDEN, "Density must be non-negative");
     if (bits & PRHF_STATUS_BADGROUP) return fail(PRHF_EINVAL, "ray_group outside [0, n_groups)");
     if (bits & PRHF_STATUS_BADINDEX) return fail(PRHF_EINVAL, "profile_index outside [0, n_prof)");
@@ -273,8 +276,11 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     if (post && (!post->vh_obs || (!post->residual && !post->cost)))
         return fail(PRHF_EINVAL, "null array pointer");
     if (n_freq < 1 || n_prof < 0 || n_alt < 1) return fail(PRHF_EINVAL, "bad shape");
-    if (n_alt > kMaxAlt) return fail(PRHF_EINVAL, "n_alt %lld exceeds the LDS-resident limit %lld",
-                                     (long long)n_alt, kMaxAlt);
+    if (n_alt > kMaxAltTall) return fail(PRHF_EINVAL, "n_alt %lld exceeds the limit of %lld levels",
+                                         (long long)n_alt, kMaxAltTall);
+    // Profiles of more levels than LDS holds are staged in global memory and take the generic loop (vfo_tall_kernel):
+    // no main loop, no candidate list, no short-grid kernels - the same values as any profile that leaves those paths
+    const bool tall = n_alt > kMaxAlt;
     if (n_freq > (1 << 20)) return fail(PRHF_EINVAL, "n_freq too large");
     if (prof_stride < n_alt || (alt_stride != 0 && alt_stride < n_alt))
         return fail(PRHF_EINVAL, "row stride shorter than a row");
@@ -327,7 +333,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     int launch_tier = 0;
     bool want_pairs = false;
     // resident workgroups: LDS admits two per CU up to 80 KiB each, else one
-    const long long wg_slots = (long long)c->cu_count * (prhf::lds_bytes_for(n_alt) <= 80 * 1024 ? 2 : 1);
+    const long long wg_slots = (long long)c->cu_count * ((tall || prhf::lds_bytes_for(n_alt) <= 80 * 1024) ? 2 : 1);
     for (int i = 0; i < n_segs; ++i) {
         const prhf_segment& u = segs[i];
         if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
@@ -362,10 +368,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         const long long seg_pairs = (u.prof_end - u.prof_begin) * n_freq;
         // (decided from the slice's shape alone: host and device callers must get the same arithmetic)
         const bool table_is_cheap = seg_pairs >= 4096 || u.n_points >= 2048;
-        s.lean = ((s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
+        s.lean = (!tall && (s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
                   table_is_cheap) ? 1 : 0;
         want_pairs = want_pairs || s.lean != 0;
-        s.thread_scan = ((double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
+        s.thread_scan = (!tall && (double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
         plan_slice(s, n_freq, wg_slots, kn);
         out_rows = std::max<long long>(out_rows, u.out_offset / n_freq + (u.prof_end - u.prof_begin));
     }
@@ -379,7 +385,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             // (grids shorter than the general kernel's main loop takes - lean_min_points - are theirs too: the pair
             //  table is built for them)
             const long long slice_pairs = (s.prof_end - s.prof_begin) * n_freq;
-            const bool table = s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints);
+            const bool table = !tall && (s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints));
             const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && table && s.chunks == 1 &&
                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
                                   n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && short_queue > 0;
@@ -599,8 +605,13 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 #endif
     a.n_blocks = blocks;
-    a.no_candidates = kNoCandidates;
-    if (n_short > 0 || n_shortx > 0 || (kPersistent && blocks > wg_slots))
+    a.no_candidates = kNoCandidates || tall;
+    if (tall && blocks > 0) {
+        a.tall_stride = prhf::tall_slab_bytes(n_alt);
+        if ((rc = ensure(c, c->tall, (size_t)std::min(blocks, wg_slots) * a.tall_stride)) != PRHF_OK) return rc;
+        a.tall = static_cast<unsigned char*>(c->tall.p);
+    }
+    if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots))
         HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 5 * sizeof(unsigned), c->stream));     // the launches' block queues
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
@@ -609,11 +620,12 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // 7.94 ms.)  Fork and join by events; a launch of one kind stays on the caller's stream.
     auto launch_general = [&]() -> int {
         long long grid_blocks = blocks;
-        if (kPersistent && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
+        if ((kPersistent || tall) && blocks > wg_slots) {    // persistent workgroups pulling blocks from a queue (vfo_kernel)
             a.queue = c->d_status + 1;
             grid_blocks = wg_slots;
         }
-        HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+        if (tall) HIP_TRY(prhf::launch_vfo_tall(a, grid_blocks, c->stream));
+        else HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
         return PRHF_OK;
     };
     const bool any_short = n_short > 0 || n_shortx > 0;
@@ -813,6 +825,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->levels.p) (void)hipFree(c->levels.p);
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
+    if (c->tall.p) (void)hipFree(c->tall.p);
     for (int g = 0; g < c->n_host_grids; ++g) {
         if (c->host_grid[g].mult.p) (void)hipFree(c->host_grid[g].mult.p);
         if (c->host_grid[g].pairs.p) (void)hipFree(c->host_grid[g].pairs.p);

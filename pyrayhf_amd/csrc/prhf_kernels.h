@@ -13,7 +13,7 @@
 #define PRHF_STATUS_PEAK0  0x2
 #define PRHF_STATUS_BADINDEX 0x4    // a ray's profile_index outside [0, n_prof) (tracers)
 #define PRHF_STATUS_WORDS 8         // one word of host-visible memory per status bit (post_status)
-#define PRHF_STATUS_NANINPUT 0x10   // NaN in a profile's density or altitude column, or in |B| / psi below its peak
+#define PRHF_STATUS_NANINPUT 0x10   // NaN in a profile's altitude column, or in |B| / psi below its peak
 #define PRHF_STATUS_BADGROUP 0x8    // a ray's ray_group outside [0, n_groups) (grouped tracer launch)
 
 #ifndef PRHF_BLOCK_THREADS
@@ -95,6 +95,9 @@ struct KArgs {
     unsigned* leftover;              // [0] count, [1..] block indices of the profiles the short-grid kernel does not take
     const unsigned* block_list;      // general kernel: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
     int short_queue;                 // entries of the short-grid kernel's LDS queue
+    // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
+    unsigned char* tall;
+    unsigned long long tall_stride;
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 
@@ -103,6 +106,13 @@ struct KArgs {
 inline size_t lds_bytes_for(long long n_alt) {
     return (size_t)(n_alt + 1) * PRHF_NODE_BYTES + (size_t)n_alt * 16 + PRHF_HINT_BUCKETS * 2 + PRHF_MAX_CAND * 2 +
            PRHF_RED_DOUBLES * 8;
+}
+
+// ... of a tall launch (vfo_tall_kernel): hints, candidate list (unused), reduction scratch; the staged profile
+// itself - the first two terms of lds_bytes_for - is a slab of global memory per workgroup
+inline size_t lds_bytes_tall() { return PRHF_HINT_BUCKETS * 2 + PRHF_MAX_CAND * 2 + PRHF_RED_DOUBLES * 8; }
+inline size_t tall_slab_bytes(long long n_alt) {
+    return (((size_t)(n_alt + 1) * PRHF_NODE_BYTES + (size_t)n_alt * 16) + 255) & ~(size_t)255;
 }
 
 // LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
@@ -142,6 +152,8 @@ hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* t
 // a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull
 // block indices from the queue, else grid_blocks must equal a.n_blocks
 hipError_t launch_vfo(const KArgs& a, long long grid_blocks, int tier, size_t lds_bytes, hipStream_t stream);
+// profiles of more than 1400 levels: a.tall holds grid_blocks slabs of a.tall_stride >= tall_slab_bytes(n_alt) bytes
+hipError_t launch_vfo_tall(const KArgs& a, long long grid_blocks, hipStream_t stream);
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);

@@ -425,12 +425,17 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     double amin = __builtin_inf();
-    int nan_in = 0;                                // NaN inputs are an error (PRHF_STATUS_NANINPUT): np.argmax / np.interp
-    for (int i = tid; i < n_alt; i += THREADS) {   // would propagate them into every frequency of the profile
+    // np.argmax ranks a NaN above every number and returns the first one (library.py:371): a density column padded
+    // with NaN is cut at the padding, exactly as the reference cuts it (fixture G13 `nanpad`).  A NaN altitude makes
+    // the reference's np.min(alt) - and with it the whole trace - NaN (:507): that is reported as an error
+    // (PRHF_STATUS_NANINPUT), like a NaN in |B| or psi below the peak (phase 2).
+    int nan_in = 0;
+    for (int i = tid; i < n_alt; i += THREADS) {
         const double v = den[i], al = alt[i];
-        if (v > bv) { bv = v; bi = i; }
+        const double key = (v != v) ? __builtin_inf() : v;
+        if (key > bv) { bv = key; bi = i; }
         amin = fmin(amin, al);
-        nan_in |= (v != v || al != al) ? 1 : 0;
+        nan_in |= (al != al) ? 1 : 0;
     }
     double fm = __builtin_inf();
     for (int i = tid; i < n_freq; i += THREADS) fm = fmin(fm, fabs(freq[i]));
@@ -1721,14 +1726,31 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
 }
 
 // TIER_SEL 0 / 1: every slice in that tier; 2: each slice in its own tier (mixed launches).
-template <int TIER_SEL, int THREADS>
-__global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(const KArgs a) {
+// TALL: profiles of more levels than LDS holds (the reference has no limit, library.py:371-375).  The staged
+// profile - nodes, f_N^2, g_p |B| - then lives in a slab of global memory that belongs to this workgroup
+// (KArgs::tall, one slab per resident workgroup: the launch is persistent whenever it has more blocks than slots),
+// and only the hint table, the reduction scratch and the counters stay in LDS.  Every device function takes the
+// staged arrays as generic pointers; the main loop, which addresses its nodes as LDS words, is switched off by the
+// host for such launches (SegDev::lean = 0, no candidate list), so a tall profile runs through the generic loop:
+// same arithmetic as any other profile that leaves the main loop, about three times slower than the LDS path.
+template <int TIER_SEL, int THREADS, bool TALL>
+__device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_alt = (int)a.n_alt;
-    Node* nodes = reinterpret_cast<Node*>(smem);                        // n_alt + 1 nodes
-    double* pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
+    Node* nodes;
+    double* pf2;
+    unsigned short* hint;
+    if (TALL) {
+        unsigned char* slab = a.tall + (size_t)blockIdx.x * a.tall_stride;
+        nodes = reinterpret_cast<Node*>(slab);
+        pf2 = reinterpret_cast<double*>(slab + (size_t)(n_alt + 1) * sizeof(Node));
+        hint = reinterpret_cast<unsigned short*>(smem);
+    } else {
+        nodes = reinterpret_cast<Node*>(smem);                          // n_alt + 1 nodes
+        pf2 = reinterpret_cast<double*>(smem + (size_t)(n_alt + 1) * sizeof(Node));
+        hint = reinterpret_cast<unsigned short*>(pf2 + 2 * (size_t)n_alt);
+    }
     double* gb = pf2 + n_alt;
-    unsigned short* hint = reinterpret_cast<unsigned short*>(gb + n_alt);
     unsigned short* cand = hint + kHintBuckets;
     double* red = reinterpret_cast<double*>(cand + PRHF_MAX_CAND);
 
@@ -1815,6 +1837,16 @@ __global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(c
         if (ticket >= n_blocks) break;
         bid = list ? (long long)list[1 + ticket] : ticket;
     }
+}
+
+template <int TIER_SEL, int THREADS>
+__global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_kernel(const KArgs a) {
+    vfo_kernel_body<TIER_SEL, THREADS, false>(a);
+}
+// (one instantiation: each slice in its own tier)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, PRHF_MIN_WAVES_PER_SIMD) void vfo_tall_kernel(const KArgs a) {
+    vfo_kernel_body<2, THREADS, true>(a);
 }
 
 // Pair table of the fast tier's main loop: (m_i, m_i+1 - m_i) side by side, one 16-byte load per
@@ -1975,8 +2007,10 @@ hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_b
         hipLaunchKernelGGL((vfo_kernel<0, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
     else if (tier == 1)
         hipLaunchKernelGGL((vfo_kernel<1, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
-    else
+    else if (tier == 2)
         hipLaunchKernelGGL((vfo_kernel<2, THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL((vfo_tall_kernel<THREADS>), dim3((unsigned)n_blocks), dim3(THREADS), lds_bytes, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (int s = 0; s < a.n_segs; ++s) {
@@ -2177,6 +2211,11 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
         __builtin_nontemporal_store(h, a.out_crit + row + i);
         __builtin_nontemporal_store((long long)i, a.out_ind + row + i);
     }
+}
+
+hipError_t launch_vfo_tall(const KArgs& a, long long grid_blocks, hipStream_t stream) {
+    if (!a.tall || a.tall_stride < tall_slab_bytes(a.n_alt)) return hipErrorInvalidValue;
+    return launch_vfo(a, grid_blocks, 3, lds_bytes_tall(), stream);
 }
 
 hipError_t launch_regrid(const RegridArgs& a, size_t lds_bytes, hipStream_t stream) {

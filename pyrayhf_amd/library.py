@@ -321,13 +321,14 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     peak is the first level (the reference fails with IndexError there too), and
     ``ValueError`` on shape mismatch (the reference only logs, library.py:487-488).
 
-    Where this differs from the reference, on purpose: a profile may have at most 1400 levels (its
-    bottomside is held in the GPU's local memory; the reference has no limit) - ``ValueError``
-    beyond; a NaN in ``den`` or ``alt``, or in ``bmag`` / ``bpsi`` below the density peak, raises
-    ``ValueError`` (the reference lets ``np.argmax`` / ``np.interp`` spread it over the profile's
-    whole trace); a frequency that is not a positive finite number gives NaN for that frequency
-    and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for a
-    negative frequency).
+    Where this differs from the reference, on purpose: a NaN in ``alt``, or in ``bmag`` / ``bpsi``
+    below the density peak, raises ``ValueError`` (the reference lets ``np.min`` / ``np.interp`` spread
+    it over the profile's trace); a frequency that is not a positive finite number gives NaN for that
+    frequency and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for
+    a negative frequency).  A density column padded with NaN is cut at the first NaN, which is what
+    the reference's ``np.argmax`` does (library.py:371).  Profiles of more than 1400 levels (up to
+    65 535) are supported but slower: their bottomside does not fit the GPU's local memory and is
+    staged in global memory instead (about three times the time per grid point).
     """
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):

@@ -237,13 +237,27 @@ def test_error_behaviour(lib):
         keep[[7, 60]] = False
         assert np.isnan(vh[:, ~keep]).all() and np.array_equal(vh[:, keep], want[:, keep], equal_nan=True), mode
     # NaN in a profile is an error (the reference lets np.argmax / np.interp spread it over the whole profile)
-    for col in ("den", "alt", "bmag", "bpsi"):
+    for col in ("alt", "bmag", "bpsi"):
         for n, mode in ((10, "O"), (200, "O"), (2000, "X")):
             bad = {k: g5[k].copy() for k in ("den", "bmag", "bpsi")}
             alt5 = np.tile(g5["alt"], (64, 1))
             (alt5 if col == "alt" else bad[col])[11, 3] = np.nan         # level 3: below every peak
             with pytest.raises(ValueError, match="NaN in a profile"):
                 lib.vertical_forward_operator(g5["freq"], bad["den"], bad["bmag"], bad["bpsi"], alt5, mode, n)
+    # ... except in the density: np.argmax ranks a NaN as the maximum (library.py:371), so the column is cut there
+    from oracle import vfo_numpy as orc
+    cut = g5["den"].copy()
+    cut[11, 40:] = np.nan                                                # profile 11: NaN from level 40 up
+    for n, mode in ((200, "O"), (2000, "X")):
+        got = lib.vertical_forward_operator(g5["freq"], cut, g5["bmag"], g5["bpsi"], g5["alt"], mode, n)
+        with np.errstate(all="ignore"):
+            want11 = orc.virtual_heights(g5["freq"], cut[11], g5["bmag"][11], g5["bpsi"][11], g5["alt"], mode, n)
+        clean = lib.vertical_forward_operator(g5["freq"], g5["den"], g5["bmag"], g5["bpsi"], g5["alt"], mode, n)
+        rows = np.arange(64) != 11
+        assert np.array_equal(got[rows], clean[rows], equal_nan=True)
+        assert_masks(got[11], want11)
+        err, ok = rel_err(got[11], want11)
+        assert err.max(initial=0.0) <= (1e-8 if mode == "X" else 1e-5), (mode, err.max())
     top = g5["bmag"].copy()
     top[:, -1] = np.nan                                                  # above the peak: never read, as in the reference
     ok_vh = lib.vertical_forward_operator(g5["freq"], g5["den"], top, g5["bpsi"], g5["alt"], "X", 2000)
@@ -577,3 +591,74 @@ def test_short_grid_kernels_every_shape(lib):
             with np.errstate(all="ignore"):
                 want = vfo_numpy.virtual_heights_batch(*args, "O", n)
             assert_o_mode(got_o, want, oracle_noise(*args, "O", n, runs=12), min_within=0.99)
+
+
+# ---- fixture G13: profiles taller than LDS holds, NaN-padded densities (made by running the reference) ----------
+
+@pytest.mark.parametrize("case,mode,n", [("tall_day", "O", 200), ("tall_day", "X", 2000),
+                                         ("tall_rag", "O", 200), ("tall_rag", "X", 500)])
+def test_profiles_of_more_than_1400_levels_g13(lib, case, mode, n):
+    """The reference has no limit on the number of levels (library.py:371-375).  3 096 / 2 600 levels (uniform /
+    irregular spacing) do not fit LDS: vfo_tall_kernel stages them in global memory."""
+    g = load_golden("g13_tall_nanpad.npz")
+    a = [g[f"{case}_{k}"] for k in ("freq", "den", "bmag", "bpsi", "alt")]
+    assert a[4].size > 1400
+    vh = lib.vertical_forward_operator(*a, mode, n)
+    want = g[f"{case}_{mode}_{n}_vh"]
+    if mode == "X":
+        print(case, "X", n, "max rel err", assert_x_mode(vh, want))
+    else:
+        noise = combined_noise(g[f"{case}_O_{n}_noise"], oracle_noise(*a, "O", n, runs=8, seed=13))
+        print(case, "O", n, "max rel err", assert_o_mode(vh, want, noise))
+
+
+def test_tall_profiles_in_batches_and_work_lists(lib):
+    """A batch of tall profiles against the C oracle - 24 profiles x 48 frequencies x 2000 points are cut into 528
+    blocks, more than the 512 workgroup slots: a persistent launch, every workgroup re-using its slab; 64 points:
+    144 blocks, one slab each - and a mixed work list over them against the single-slice calls."""
+    from oracle import vfo_c
+    from pyrayhf_amd import synth
+    a0, den0, bmag0, bpsi0 = synth.chapman_profiles(24, 1313)
+    alt = np.arange(80.0, 700.0, 0.25)                                    # 2 480 levels
+    den, bmag, bpsi = (np.array([np.interp(alt, a0, r) for r in x]) for x in (den0, bmag0, bpsi0))
+    freq = np.linspace(1.0, 12.0, 48)
+    for mode, n in (("X", 2000), ("O", 200), ("X", 64)):
+        got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n)
+        want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n)
+        if mode == "X":
+            assert_x_mode(got, want)
+        else:
+            assert_o_mode(got, want, oracle_noise(freq, den, bmag, bpsi, alt, "O", n, runs=6, seed=5))
+    segs = [(0, 10, "O", 200), (10, 24, "X", 2000)]
+    mixed = lib.vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segs)
+    assert np.array_equal(mixed[:10], lib.vertical_forward_operator(freq, den[:10], bmag[:10], bpsi[:10], alt, "O", 200),
+                          equal_nan=True)
+    assert np.array_equal(mixed[10:], lib.vertical_forward_operator(freq, den[10:], bmag[10:], bpsi[10:], alt, "X", 2000),
+                          equal_nan=True)
+    # one tall profile, many points: the chunked launch (every workgroup stages the profile into its own slab)
+    one = lib.vertical_forward_operator(freq, den[3], bmag[3], bpsi[3], alt, "X", 20000)
+    assert_x_mode(one, vfo_c.virtual_heights_batch(freq, den[3:4], bmag[3:4], bpsi[3:4], alt, "X", 20000)[0])
+    # a profile of 1 401 levels is tall, one of 1 400 is not: the same inputs cut at either size agree where both see
+    # the whole bottomside
+    k = int(np.argmax(den[5])) + 2
+    assert k < 1400
+    lo = lib.vertical_forward_operator(freq, den[5, :1400], bmag[5, :1400], bpsi[5, :1400], alt[:1400], "X", 2000)
+    hi = lib.vertical_forward_operator(freq, den[5, :1401], bmag[5, :1401], bpsi[5, :1401], alt[:1401], "X", 2000)
+    assert_x_mode(hi, lo, tol=1e-9)
+
+
+@pytest.mark.parametrize("first", [300, 200])
+def test_density_padded_with_nan_is_cut_at_the_padding_g13(lib, first):
+    """np.argmax returns the first NaN (library.py:371): a density column padded with NaN from level `first` up is
+    evaluated as the reference evaluates it - levels [0, first)."""
+    g = load_golden("g13_tall_nanpad.npz")
+    a = [g["nanpad_freq"], g[f"nanpad_{first}_den"], g["nanpad_bmag"], g["nanpad_bpsi"], g["nanpad_alt"]]
+    vx = lib.vertical_forward_operator(*a, "X", 200)
+    assert_x_mode(vx, g[f"nanpad_{first}_X_200_vh"])
+    vo = lib.vertical_forward_operator(*a, "O", 200)
+    noise = combined_noise(g[f"nanpad_{first}_O_200_noise"], oracle_noise(*a, "O", 200, runs=8, seed=first))
+    assert_o_mode(vo, g[f"nanpad_{first}_O_200_vh"], noise)
+    # the same on GPU-resident inputs
+    import torch
+    t = [torch.as_tensor(np.asarray(x, dtype=np.float64), device="cuda:0") for x in a]
+    assert np.array_equal(lib.vertical_forward_operator(*t, "X", 200).cpu().numpy(), vx, equal_nan=True)

@@ -121,7 +121,8 @@ def test_non_uniform_grid_at_full_resolution():
 @pytest.mark.parametrize("n_alt", [700, 1400])
 def test_tall_profiles_one_workgroup_per_cu(n_alt):
     """More than 674 levels: a profile's nodes no longer fit twice into a CU's LDS (one workgroup per CU);
-    1400 is the limit of the interface, 1401 is refused."""
+    1400 is the most LDS holds - 1401 levels take the global-memory path (vfo_tall_kernel, round 3: the reference has
+    no limit), 65 536 are refused (level indices travel as uint16)."""
     from oracle import vfo_c
     from pyrayhf_amd import library
     if not vfo_c.available():
@@ -142,8 +143,15 @@ def test_tall_profiles_one_workgroup_per_cu(n_alt):
         assert ok.sum() > 50 and err.max() <= 1e-8, (n_points, err.max())
     if n_alt == 1400:
         alt2 = np.linspace(80.0, 700.0, 1401)
-        with pytest.raises(ValueError):
-            library.vertical_forward_operator(freq, np.ones((1, 1401)), np.ones((1, 1401)), np.ones((1, 1401)), alt2, "X", 200)
+        cols = [np.stack([np.interp(alt2, alt, r) for r in x]) for x in (den, bmag, bpsi)]
+        want = vfo_c.virtual_heights_batch(freq, *cols, alt2, "X", 320)
+        got = library.vertical_forward_operator(freq, *cols, alt2, "X", 320)
+        assert_masks(got, want)
+        err, ok = rel_err(got, want)
+        assert ok.sum() > 50 and err.max() <= 1e-8, err.max()
+        with pytest.raises(ValueError, match="exceeds the limit"):
+            library.vertical_forward_operator(freq, np.ones((1, 65536)), np.ones((1, 65536)), np.ones((1, 65536)),
+                                              np.linspace(80.0, 700.0, 65536), "X", 200)
 
 
 @pytest.mark.parametrize("seed", [5000, 5001, 5002, 5003, 5004, 5005])

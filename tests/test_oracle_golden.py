@@ -197,3 +197,28 @@ def test_snell_spherical_tracer_g9():
             else:
                 assert np.isnan(r["x"]) and set(r) == {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint",
                                                         "z_midpoint", "ground_range_km"}      # library.py:1577-1583
+
+
+def test_tall_and_nan_padded_profiles_g13():
+    """Profiles of 3 096 / 2 600 levels and densities padded with NaN (np.argmax returns the first NaN,
+    library.py:371), as the reference evaluates them."""
+    g = load_golden("g13_tall_nanpad.npz")
+    with np.errstate(all="ignore"):
+        for case, runs in (("tall_day", (("O", 200), ("X", 2000))), ("tall_rag", (("O", 200), ("X", 500)))):
+            a = [g[f"{case}_{k}"] for k in ("freq", "den", "bmag", "bpsi", "alt")]
+            for mode, n in runs:
+                assert same_bits(orc.virtual_heights(*a, mode, n), g[f"{case}_{mode}_{n}_vh"]), (case, mode, n)
+        for first in (300, 200):
+            a = [g["nanpad_freq"], g[f"nanpad_{first}_den"], g["nanpad_bmag"], g["nanpad_bpsi"], g["nanpad_alt"]]
+            for mode in "OX":
+                assert same_bits(orc.virtual_heights(*a, mode, 200), g[f"nanpad_{first}_{mode}_200_vh"]), (first, mode)
+    # the plain-C restatement ranks a NaN density the same way
+    from oracle import vfo_c
+    if vfo_c.available():
+        a = [g["nanpad_freq"], g["nanpad_200_den"][None, :], g["nanpad_bmag"][None, :], g["nanpad_bpsi"][None, :],
+             g["nanpad_alt"]]
+        got = vfo_c.virtual_heights_batch(*a, "X", 200)[0]
+        want = g["nanpad_200_X_200_vh"]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = np.isfinite(want)
+        assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 1e-12
