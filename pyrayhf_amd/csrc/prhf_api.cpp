@@ -59,6 +59,8 @@ struct Knobs {
     double shortx_kernel = 1;          // 0: X-mode grids of up to 4096 points stay in the general kernel
     double short_concurrent = 1;       // 0: short-grid and general launch of a mixed list one after the other
     double short_queue = 0;            // > 0: the short-grid kernel's queue holds exactly this many entries (tests)
+    double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
+                                       // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
 struct KnobName {
     const char* name;
@@ -80,6 +82,7 @@ const KnobName kKnobNames[] = {
     {"shortx_kernel", &Knobs::shortx_kernel, 0, 1},
     {"short_concurrent", &Knobs::short_concurrent, 0, 1},
     {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
+    {"local_chunks", &Knobs::local_chunks, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -220,8 +223,28 @@ void plan_slice(prhf::SegDev& s, long long n_freq, long long wg_slots, const Kno
         chunk_len = (((N + want - 1) / want + 63) / 64) * 64;
         chunks = (N + chunk_len - 1) / chunk_len;
     }
+    s.slots = 0;
+    if (chunks > 1 && kn.local_chunks != 0) {
+        // Block-local chunks: S = 2, 4 or 8 slots per pair (the power of two at or below what the waves target asks
+        // for), the pair's <= S chunks on consecutive waves of one workgroup, 8 / S pairs per workgroup.  One profile x
+        // 174 frequencies x 20000 points: 174 workgroups of 8 chunks instead of 501 workgroups + a second kernel.
+        long long want = std::min<long long>(std::min((kTargetWaves + pairs - 1) / pairs, (N + 255) / 256), kWavesPerBlock);
+        long long S = 1;
+        while (S * 2 <= want) S *= 2;
+        if (S > 1) {
+            chunk_len = (((N + S - 1) / S + 63) / 64) * 64;
+            chunks = (N + chunk_len - 1) / chunk_len;          // <= S
+            s.slots = (int)S;
+        }
+    }
     s.chunks = (int)chunks;
     s.chunk_len = (int)chunk_len;
+    if (s.slots > 0) {
+        s.blocks_per_prof = (int)((n_freq * s.slots + kWavesPerBlock - 1) / kWavesPerBlock);
+        s.tail_prof = P;
+        s.tail_bpp = s.blocks_per_prof;
+        return;
+    }
     const long long items = n_freq * chunks;
     long long waves = std::max<long long>(1, std::min(items, (kTargetWaves + std::max<long long>(P, 1) - 1) /
                                                                  std::max<long long>(P, 1)));
@@ -428,7 +451,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.prio = std::max(0, 3 - i);               // (sorted: the slice with the longest workgroups first)
         s.block_begin = blocks;
         blocks += s.tail_prof * s.blocks_per_prof + (P - s.tail_prof) * s.tail_bpp;
-        if (s.chunks > 1) {
+        if (s.chunks > 1 && s.slots == 0) {
             s.partial_off = partial_elems;
             s.altmin_off = altmin_elems;
             partial_elems += P * n_freq * s.chunks;

@@ -54,6 +54,8 @@ struct SegDev {
     int mode, n_points;
     int chunks;                      // wave-sized work items per pair
     int chunk_len;                   // grid points per chunk (multiple of 64)
+    int slots;                       // > 0: block-local chunks - a pair's chunks (<= slots, a power of two <= 8) are the
+                                     // consecutive waves of ONE workgroup, which adds them up itself (run_items)
     int blocks_per_prof;
     int tier;                        // 0 faithful, 1 fast (read by the mixed-tier kernel)
     // The last profiles of a long slice may be cut into more, shorter workgroups so that the launch

@@ -1607,7 +1607,7 @@ template <int MODE, int TIER, int THREADS>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
                                           const unsigned short* cand, const BlockInfo& info, long long prof_local,
-                                          int block_in_prof, int blocks_per_prof, int* item_next, const double* red) {
+                                          int block_in_prof, int blocks_per_prof, int* item_next, double* red) {
     constexpr int W = THREADS / 64;
     const int lane = threadIdx.x & 63;
     const double* keep = kept_scalars<THREADS>(red);
@@ -1620,21 +1620,38 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
     const double2* pairs = (a.pairs && sg.lean) ? reinterpret_cast<const double2*>(a.pairs) + sg.mult_off : nullptr;
     const long long pair_base = prof_local * F;
     const int first_item = block_in_prof * W, round_items = blocks_per_prof * W;
-    // Items are handed out first come, first served.  The SIMD arbiter favours its older waves: with a
+    // Few pairs on a long grid (one profile, the reference's own call; SegDev::slots > 0): a pair is cut into C <= S
+    // chunks that all live in THIS workgroup - wave w takes item (block_in_prof * W + w): frequency item / S, chunk
+    // item % S, S = 2, 4 or 8 slots per pair - and the workgroup adds the chunk sums itself, in chunk order, through
+    // LDS: no scratch in global memory, no second kernel (the launch of vfo_finalize_kernel behind a 21 us kernel
+    // cost 7 us), same value whichever wave finishes first.
+    // Otherwise items are handed out first come, first served.  The SIMD arbiter favours its older waves: with a
     // fixed share per wave, waves 0-3 of a workgroup were done at 70 % of its life (tools/wave_trace.py)
     // and their slots sat empty for the rest.  Which wave computes a pair does not change its value.
     // Everything that steers this loop is wave-uniform and kept in SGPRs (uniform()), so that the
     // compiler emits scalar branches and not exec-masked loops around the wave-level operations inside.
     // Every lane takes part in the atomic (the compiler folds the 64 increments into one LDS add of 64
     // and hands lane 0 the old value): no lane-divergent branch in this loop's control flow.
+    // (One loop, one copy of the item's code for both kinds: a second call site costs the kernel 8 - 13 VGPRs.)
+    static_assert(11 * W + 8 <= PRHF_RED_DOUBLES, "reduction scratch too small");
+    const int S = uniform(sg.slots), wave = threadIdx.x >> 6;
+    const bool local = S > 0;
+    double* part = red + 10 * W + 8;                   // (behind the kept scalars; rows 0 .. 9 may still be read by a
+    if (local && lane == 0) part[wave] = 0.0;          //  wave that left stage_profile early)
     auto next_item = [&]() {
         const int u = uniform(atomicAdd(item_next, 1)) >> 6;
         // this block's items: rounds of W, interleaved with the profile's other blocks
         return uniform((u / W) * round_items + first_item + (u % W));
     };
-    for (int t = next_item(); t < T; t = next_item()) {
+    int t = local ? uniform(block_in_prof * W + wave) : next_item();
+    const int t_end = local ? uniform(min(F * S, t + 1)) : T;      // (block-local chunks: this wave's one item)
+    for (; t < t_end; t = local ? t_end : next_item()) {
         int f = t, c = 0;
-        if (info.n_cand >= 0) {
+        if (local) {
+            f = t / S;
+            c = t % S;
+            if (c >= C) break;                     // (fewer chunks than slots: an idle wave)
+        } else if (info.n_cand >= 0) {
             f = uniform((int)cand[t]);
         } else if (C > 1) {                        // (unchunked launches spare the integer division)
             f = t % F;
@@ -1666,13 +1683,26 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
             }
         }
         if (lane == 0) {
-            if (C == 1) {
+            if (local) {
+                part[wave] = reflects ? result : qnan();
+            } else if (C == 1) {
                 // :290-292: exact zero means every term was NaN -> NaN; then add min(alt)
                 const double vh = (reflects && result != 0.0) ? result + keep[kKeepAltMin] : qnan();
                 a.out[sg.out_off + pair_base + f] = vh;
             } else {
                 a.partial[sg.partial_off + (pair_base + f) * C + c] = reflects ? result : qnan();
             }
+        }
+    }
+    if (local) {
+        __syncthreads();
+        const int item = block_in_prof * W + wave;
+        const int f = item / S;
+        if (f < F && item % S == 0 && lane == 0) {
+            double sum = 0.0;
+            for (int cc = 0; cc < C; ++cc) sum = sum + part[wave + cc];
+            // :290-292: exact zero means every term was NaN -> NaN; then add min(alt) (vfo_finalize_kernel's rule)
+            a.out[sg.out_off + pair_base + f] = (sum == sum && sum != 0.0) ? sum + keep[kKeepAltMin] : qnan();
         }
     }
 }
@@ -1714,7 +1744,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
 #endif
     if (threadIdx.x == 0 && block_in_prof == 0) {
         if (info.bad) post_status(a.status, (unsigned)info.bad);
-        if (sg.chunks > 1) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
+        if (sg.chunks > 1 && sg.slots == 0) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
     }
     if (sg.mode == PRHF_KMODE_O)
         run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
@@ -2014,7 +2044,7 @@ hipError_t launch_vfo(const KArgs& a, long long n_blocks, int tier, size_t lds_b
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (int s = 0; s < a.n_segs; ++s) {
-        if (a.seg[s].chunks <= 1) continue;
+        if (a.seg[s].chunks <= 1 || a.seg[s].slots > 0) continue;     // (block-local chunks are added up by their workgroup)
         const long long n_pairs = (a.seg[s].prof_end - a.seg[s].prof_begin) * a.n_freq;
         if (n_pairs <= 0) continue;
         const unsigned blocks = (unsigned)((n_pairs + 255) / 256);

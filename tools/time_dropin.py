@@ -3,6 +3,9 @@ import sys, os, json, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from pyrayhf_amd import library, synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _options
+opts = _options.apply()                                   # PRHF_TOOL_OPTIONS="local_chunks=0" for A/B runs
 alt, den, bmag, bpsi = synth.chapman_profiles(4, 99)
 freq = synth.sounder_frequencies(1)
 for mode, n in (("O", 200), ("X", 200), ("O", 2000), ("X", 20000)):
@@ -24,4 +27,4 @@ for mode, n in (("O", 200), ("X", 200), ("O", 2000), ("X", 20000)):
     binding = (time.perf_counter() - t1) / reps
     ctx.vfo_batch = real
     print(json.dumps({"call": f"vertical_forward_operator(174 freqs, 1 profile, '{mode}', {n}) on NumPy arrays", "us_per_call": 1e6 * dt, "python_binding_us": 1e6 * binding,
-                      "kernel_us": 1e3 * library.last_kernel_ms(), "finite": int(np.isfinite(vh).sum())}), flush=True)
+                      "kernel_us": 1e3 * library.last_kernel_ms(), "finite": int(np.isfinite(vh).sum()), "options": opts}), flush=True)
