@@ -131,8 +131,11 @@ int prhf_ctx_set_option(prhf_ctx* ctx, const char* name, double value);
  *               buffer that decreases; a device-resident grid is the caller's responsibility)
  *   A frequency that is not a positive finite number gives a NaN column (the reference: NaN for 0 and NaN).
  *   vh_out      (n_prof, n_freq) row-major
- *   A NaN in den ranks as the column's maximum, the first one wins (np.argmax, library.py:371): a density column
- *   padded with NaN is cut at the padding.  A NaN in alt, or in bmag / bpsi below the peak, is PRHF_EINVAL.
+ *   NaN inputs are not errors; they behave as in the reference: a NaN in den ranks as the column's maximum, the
+ *   first one wins (np.argmax, library.py:371: a density column padded with NaN is cut at the padding); a NaN in alt
+ *   makes the profile's row NaN (:507), and so does a NaN in bmag below the peak in X mode (:389); in O mode, and for
+ *   a NaN in bpsi, the grid points of the two segments next to that level drop out of the sum (:288).
+ *   (prhf_regrid_f64 refuses a NaN in alt, or in bmag / bpsi below the peak: PRHF_EINVAL.)
  * Limits: n_alt <= 65535, n_freq <= 2^20, n_points >= 1.  Up to 1400 levels a profile's bottomside is held in LDS;
  * taller profiles are staged in global memory (one slab per resident workgroup, allocated by the context) and
  * take the generic loop - same values, about three times the time per grid point.

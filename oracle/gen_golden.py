@@ -464,7 +464,9 @@ def gen_tall(lib):
       tall_day   the Day example resampled to 0.2 km (3 096 levels), 174 freqs: O/200 with its noise floor, X/2000
       tall_rag   a Chapman layer on 2 600 levels with irregular spacing (0.05 - 0.45 km), 96 freqs: O/200, X/500
       nanpad     the Day example with den = NaN from level 300 up (above the peak at 258) and from level 200 up
-                 (below it: the layer is cut short), 174 freqs, O/200 and X/200"""
+                 (below it: the layer is cut short), 174 freqs, O/200 and X/200
+      nanfield   the Day example with a NaN in alt, bmag or bpsi at one or two levels (cases in `nanfield_cases`;
+                 the inputs are nanpad_* with that column blanked at `nanfield_<case>_levels`), {O, X} x {200, 2000}"""
     from pyrayhf_amd import synth
     g = {}
     d = load_example("Day")
@@ -495,6 +497,21 @@ def gen_tall(lib):
         g[f"nanpad_{first}_O_200_vh"], g[f"nanpad_{first}_O_200_noise"] = noise_floor(
             lib, freq, den, d["bmag"], d["bpsi"], d["alt"], "O", 200, seed=1304 + first)
         g[f"nanpad_{first}_X_200_vh"] = lib.vertical_forward_operator(freq, den, d["bmag"], d["bpsi"], d["alt"], "X", 200)
+    # NaN in the other columns (the operator reproduces the reference's behaviour): the Day example
+    # with one or two levels blanked; every case x {O, X} x {200, 2000}
+    nan_cases = {"alt_500": ("alt", [500]), "alt_100": ("alt", [100]), "bmag_100": ("bmag", [100]), "bmag_1": ("bmag", [1]),
+                 "bpsi_100": ("bpsi", [100]), "bpsi_1": ("bpsi", [1]), "bpsi_50_200": ("bpsi", [50, 200]),
+                 "bpsi_257": ("bpsi", [257]), "bmag_400": ("bmag", [400])}
+    g["nanfield_cases"] = np.array(sorted(nan_cases))
+    for name, (col, levels) in nan_cases.items():
+        a = {k: d[k].copy() for k in ("den", "bmag", "bpsi", "alt")}
+        a[col][levels] = np.nan
+        g[f"nanfield_{name}_col"] = np.array(col)
+        g[f"nanfield_{name}_levels"] = np.array(levels)
+        for mode in "OX":
+            for n in (200, 2000):
+                g[f"nanfield_{name}_{mode}_{n}_vh"] = lib.vertical_forward_operator(freq, a["den"], a["bmag"], a["bpsi"],
+                                                                                    a["alt"], mode, n)
     np.savez(os.path.join(OUT, "g13_tall_nanpad.npz"), **g)
     for k in sorted(g):
         if k.endswith("_vh"):

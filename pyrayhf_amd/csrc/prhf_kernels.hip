@@ -378,6 +378,8 @@ struct BlockInfo {
     int poly_angle;   // every segment has a 2 cos^2(psi) polynomial: 1 cubic, 2 quadratic (all u3 = 0), 3 linear (u2 = 0 too);
                       // 4: every segment in rotation form (some turn the field by 3e-4 .. 0.05 rad); 0: some need sin() per point
     int n_cand;       // entries of the candidate list (frequencies that may reflect), -1: no list, every frequency
+    int nan_b;        // a NaN in |B| below the peak: in X mode the reference's whole trace is NaN (run_block)
+    int nan_p;        // a NaN in psi below the peak
     const double* heights;   // O mode with a candidate list: reflection height of every entry (they all reflect); else null
     double a0;        // alt[0]
     double inv_w;     // hint buckets per km
@@ -393,6 +395,11 @@ template <int THREADS>
 __device__ __forceinline__ const double* kept_scalars(const double* red) { return red + 10 * (THREADS / 64); }
 
 constexpr int kHintBuckets = PRHF_HINT_BUCKETS;
+// BlockInfo::bad beyond the PRHF_STATUS_* bits: every frequency of this profile is NaN and that is NOT an error (the
+// reference returns such a row: np.min(alt) of a column with a NaN, :507; X + Y with a NaN |B| below the peak, :389,
+// :399).  post_status only looks at the PRHF_STATUS_WORDS low bits.
+constexpr int kNanRow = 0x100;
+static_assert(kNanRow >= (1 << PRHF_STATUS_WORDS), "kNanRow must not be a status bit");
 
 // -DPRHF_TRACE builds: wall-clock marks of the staging phases of the current block (thread 0 writes them)
 #ifdef PRHF_TRACE
@@ -425,10 +432,12 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     double bv = -__builtin_inf();
     int bi = 0x7fffffff;
     double amin = __builtin_inf();
-    // np.argmax ranks a NaN above every number and returns the first one (library.py:371): a density column padded
-    // with NaN is cut at the padding, exactly as the reference cuts it (fixture G13 `nanpad`).  A NaN altitude makes
-    // the reference's np.min(alt) - and with it the whole trace - NaN (:507): that is reported as an error
-    // (PRHF_STATUS_NANINPUT), like a NaN in |B| or psi below the peak (phase 2).
+    // NaN inputs behave as they do in the reference (fixture G13).  np.argmax ranks a NaN above every number and
+    // returns the first one (library.py:371): a density column padded with NaN is cut at the padding.  A NaN altitude
+    // makes np.min(alt) - and with it the whole trace - NaN (:507).  A NaN in |B| below the peak makes the X-mode
+    // trace NaN (np.maximum.accumulate of X + Y, :389, :399); in O mode, like a NaN in psi in either mode, it blanks
+    // the grid points of the two segments next to that level (np.interp), which the sum then skips (:288) - the
+    // generic loop does exactly that (phase 2 keeps such a profile out of the main loop).
     int nan_in = 0;
     for (int i = tid; i < n_alt; i += THREADS) {
         const double v = den[i], al = alt[i];
@@ -496,8 +505,10 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     info.inv_w = 0.0;
     info.inv_step = 0.0;
     const int K = info.K;
+    info.nan_b = 0;
+    info.nan_p = 0;
     if (uniform(nan_in)) {
-        info.bad = PRHF_STATUS_NANINPUT;
+        info.bad = kNanRow;
         info.K = 0;
         return info;
     }
@@ -575,6 +586,9 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
             trig = 1;
             steep |= (turn > kTrigAngle) ? 1 : 0;
         }
+        // a NaN in |B| or psi (here or at the level above: then the slopes are NaN): the generic loop, whose sum skips
+        // the blanked points one by one
+        steep |= (b != b || p != p || nd.sb != nd.sb || spsi != spsi) ? 1 : 0;
         nodes[k] = nd;
         const double fn = sqrt(d) * kPlasma;       // :96
         pf2[k] = fn * fn;                          // :136 numerator
@@ -582,11 +596,12 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         pmax = fmax(pmax, fn * fn);
         bmax = fmax(bmax, fabs(b));
         neg |= (d < 0.0) ? 1 : 0;
-        neg |= (b != b || p != p) ? 2 : 0;         // NaN in the field columns below the peak
+        neg |= (b != b) ? 2 : 0;                   // NaN in |B| below the peak
+        neg |= (p != p) ? 4 : 0;                   // ... in psi
     }
     bmax = wave_max(bmax);
     pmax = wave_max(pmax);
-    neg = (__any(neg & 1) ? 1 : 0) | (__any(neg & 2) ? 2 : 0);
+    neg = (__any(neg & 1) ? 1 : 0) | (__any(neg & 2) ? 2 : 0) | (__any(neg & 4) ? 4 : 0);
     ragged = __any(ragged) ? 1 : 0;
     // 5: some segment turns the field by more than kTrigAngle (sin() per point, generic loop), 1: some segment needs the
     // rotation form, 2: some segment keeps its cubic, 3: some keeps its quadratic, 0: all linear
@@ -623,7 +638,8 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     trig = uniform(trig);
     ragged = uniform(ragged);
     if (neg & 1) info.bad = PRHF_STATUS_NEGDEN;    // library.py:93-94
-    if (neg & 2) info.bad = PRHF_STATUS_NANINPUT;
+    info.nan_b = (neg & 2) ? 1 : 0;
+    info.nan_p = (neg & 4) ? 1 : 0;
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
@@ -687,9 +703,12 @@ template <int MODE, int TIER, bool UNMAG>
 __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_hz, double f2, double cX,
                                             double cY2, bool poly_angle, double well_conditioned) {
     double mu, mup;
+    // np.interp returns fp[j] itself for an abscissa that sits ON level j (numpy arr_interp: x == xp[j]) whatever the
+    // slope: it only shows when the slope is NaN (a NaN at level j + 1) - grid point 0 always sits on level 0
+    const double sden_ = dz == 0.0 ? 0.0 : nd.sden, sb_ = dz == 0.0 ? 0.0 : nd.sb, spsi_ = dz == 0.0 ? 0.0 : nd.spsi;
     if (TIER == 0) {
 #pragma clang fp contract(off)
-        const double den = nd.sden * dz + nd.den;      // numpy arr_interp: slope*(x - xp[j]) + fp[j]
+        const double den = sden_ * dz + nd.den;        // numpy arr_interp: slope*(x - xp[j]) + fp[j]
         if (!UNMAG) {
             // Where 1 - X is not small at any of the wave's points, the operation order does not matter
             // (both forms agree to 1e-12 there) and the reduced algebra - no divide, no sqrt - is used;
@@ -697,8 +716,8 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             const double Xq = den * cX;
             if (__all(1.0 - Xq > well_conditioned)) {
 #pragma clang fp contract(fast)
-                const double b = nd.sb * dz + nd.b;
-                const double sn = sin((nd.spsi * dz + nd.psi) * kDegToRad);
+                const double b = sb_ * dz + nd.b;
+                const double sn = sin((spsi_ * dz + nd.psi) * kDegToRad);
                 index_fast<MODE>(Xq, (b * b) * cY2, sn * sn, &mu, &mup);
                 return mup;
             }
@@ -708,25 +727,25 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
         if (UNMAG) {
             index_unmagnetised(X, &mu, &mup);
         } else {
-            const double b = nd.sb * dz + nd.b;
-            const double psi = nd.spsi * dz + nd.psi;
+            const double b = sb_ * dz + nd.b;
+            const double psi = spsi_ * dz + nd.psi;
             const double Y = (kGyro * b) / f_hz;       // :157
             index_faithful<MODE>(X, Y, psi, &mu, &mup);
         }
     } else {
 #pragma clang fp contract(fast)
-        const double den = nd.sden * dz + nd.den;
+        const double den = sden_ * dz + nd.den;
         const double X = den * cX;                     // cX = cp^2 / f^2
         if (UNMAG) {
             index_unmagnetised(X, &mu, &mup);
         } else {
-            const double b = nd.sb * dz + nd.b;
+            const double b = sb_ * dz + nd.b;
             const double Y2 = (b * b) * cY2;           // cY2 = (g_p / f)^2
             double S2;
             if (poly_angle || nd.u3 == nd.u3) {        // per segment; poly_angle: true for the whole profile
                 S2 = 1.0 - 0.5 * (nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3)));    // the nodes hold 2 cos^2
             } else {
-                const double sn = sin((nd.spsi * dz + nd.psi) * kDegToRad);
+                const double sn = sin((spsi_ * dz + nd.psi) * kDegToRad);
                 S2 = sn * sn;
             }
             index_fast<MODE>(X, Y2, S2, &mu, &mup);
@@ -1720,6 +1739,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         a.den + p * a.prof_stride, a.bmag + p * a.field_stride, a.bpsi + p * a.field_stride,
         a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
     PRHF_MARK(1);
+    if (sg.mode == PRHF_KMODE_X && info.nan_b && !info.bad) info.bad = kNanRow;     // (see stage_profile)
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     PRHF_MARK(2);
     info.n_cand = -1;
@@ -2195,7 +2215,10 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
     const double one_mhz = 1.0;     // stage_profile only needs a frequency column for the isotropic test
     const BlockInfo info = stage_profile<0, THREADS>(a.den, a.bmag, a.bpsi, a.alt, &one_mhz, 0, n_alt, nodes,
                                                      pf2, gb, hint, red);
-    if (threadIdx.x == 0 && info.bad) post_status(a.status, (unsigned)info.bad);
+    // (the standalone regrid keeps refusing NaN profiles: the operator's NaN rules - stage_profile - are about its sums)
+    if (threadIdx.x == 0 && (info.bad || info.nan_b || info.nan_p))
+        post_status(a.status, (unsigned)((info.bad & ~kNanRow) | ((info.bad & kNanRow) || info.nan_b || info.nan_p
+                                                                   ? PRHF_STATUS_NANINPUT : 0)));
     if (a.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
     const double f_hz = a.freq_hz[f];
     double h = qnan();

@@ -321,14 +321,15 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     peak is the first level (the reference fails with IndexError there too), and
     ``ValueError`` on shape mismatch (the reference only logs, library.py:487-488).
 
-    Where this differs from the reference, on purpose: a NaN in ``alt``, or in ``bmag`` / ``bpsi``
-    below the density peak, raises ``ValueError`` (the reference lets ``np.min`` / ``np.interp`` spread
-    it over the profile's trace); a frequency that is not a positive finite number gives NaN for that
-    frequency and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for
-    a negative frequency).  A density column padded with NaN is cut at the first NaN, which is what
-    the reference's ``np.argmax`` does (library.py:371).  Profiles of more than 1400 levels (up to
-    65 535) are supported but slower: their bottomside does not fit the GPU's local memory and is
-    staged in global memory instead (about three times the time per grid point).
+    NaN inputs behave as in the reference (fixture G13): a density column padded with NaN is cut at
+    the first NaN (``np.argmax``, library.py:371); a NaN in ``alt`` makes the profile's whole trace NaN
+    (``np.min(alt)``, :507), and so does a NaN in ``bmag`` below the peak in X mode (:389); in O mode -
+    and for a NaN in ``bpsi`` in either mode - the grid points of the two segments next to that level
+    drop out of the sum (:288).  A frequency that is not a positive finite number gives NaN for that
+    frequency and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for a
+    negative frequency).  Profiles of more than 1400 levels (up to 65 535) are supported but slower:
+    their bottomside does not fit the GPU's local memory and is staged in global memory instead (about
+    three times the time per grid point).
     """
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):

@@ -236,14 +236,23 @@ def test_error_behaviour(lib):
         keep = np.ones(f.size, bool)
         keep[[7, 60]] = False
         assert np.isnan(vh[:, ~keep]).all() and np.array_equal(vh[:, keep], want[:, keep], equal_nan=True), mode
-    # NaN in a profile is an error (the reference lets np.argmax / np.interp spread it over the whole profile)
+    # NaN in a profile is not an error: the result is what the reference computes (fixture G13 `nanfield`; here in a
+    # batch, where the NaN profile leaves the short-grid kernels for the general one and the others must not notice)
+    from oracle import vfo_numpy as orc_nan
     for col in ("alt", "bmag", "bpsi"):
-        for n, mode in ((10, "O"), (200, "O"), (2000, "X")):
+        for n, mode in ((10, "O"), (200, "O"), (200, "X"), (2000, "X")):
             bad = {k: g5[k].copy() for k in ("den", "bmag", "bpsi")}
             alt5 = np.tile(g5["alt"], (64, 1))
             (alt5 if col == "alt" else bad[col])[11, 3] = np.nan         # level 3: below every peak
-            with pytest.raises(ValueError, match="NaN in a profile"):
-                lib.vertical_forward_operator(g5["freq"], bad["den"], bad["bmag"], bad["bpsi"], alt5, mode, n)
+            got = lib.vertical_forward_operator(g5["freq"], bad["den"], bad["bmag"], bad["bpsi"], alt5, mode, n)
+            clean = lib.vertical_forward_operator(g5["freq"], g5["den"], g5["bmag"], g5["bpsi"], g5["alt"], mode, n)
+            rows = np.arange(64) != 11
+            assert np.array_equal(got[rows], clean[rows], equal_nan=True), (col, mode, n)
+            with np.errstate(all="ignore"):
+                want11 = orc_nan.virtual_heights(g5["freq"], bad["den"][11], bad["bmag"][11], bad["bpsi"][11], alt5[11], mode, n)
+            assert_masks(got[11], want11)
+            err, ok = rel_err(got[11], want11)
+            assert err.max(initial=0.0) <= (1e-8 if mode == "X" else 1e-5), (col, mode, n, err.max())
     # ... except in the density: np.argmax ranks a NaN as the maximum (library.py:371), so the column is cut there
     from oracle import vfo_numpy as orc
     cut = g5["den"].copy()
@@ -662,3 +671,33 @@ def test_density_padded_with_nan_is_cut_at_the_padding_g13(lib, first):
     import torch
     t = [torch.as_tensor(np.asarray(x, dtype=np.float64), device="cuda:0") for x in a]
     assert np.array_equal(lib.vertical_forward_operator(*t, "X", 200).cpu().numpy(), vx, equal_nan=True)
+
+
+def _nanfield_inputs(g, case):
+    day = load_golden("g4_day_night.npz")
+    a = {"freq": g["nanpad_freq"], "den": day["Day_den"].copy(), "bmag": day["Day_bmag"].copy(),
+         "bpsi": day["Day_bpsi"].copy(), "alt": day["Day_alt"].copy()}
+    a[str(g[f"nanfield_{case}_col"])][g[f"nanfield_{case}_levels"]] = np.nan
+    return [a[k] for k in ("freq", "den", "bmag", "bpsi", "alt")]
+
+
+@pytest.mark.parametrize("case", ["alt_100", "alt_500", "bmag_1", "bmag_100", "bmag_400", "bpsi_1", "bpsi_100",
+                                  "bpsi_257", "bpsi_50_200"])
+def test_nan_in_altitude_field_strength_or_angle_behaves_as_in_the_reference_g13(lib, case):
+    """A NaN altitude: the whole trace is NaN (np.min(alt), library.py:507).  A NaN |B| below the peak: the X-mode
+    trace is NaN (running maximum of X + Y, :389); in O mode - and a NaN psi in either mode - the grid points of the
+    two segments next to the level are blanked by np.interp and the sum skips them (:288), except a point that sits
+    ON the level below (grid point 0 on level 0: `bpsi_1`, `bmag_1`).  Above the peak nothing is read (`bmag_400`)."""
+    g = load_golden("g13_tall_nanpad.npz")
+    a = _nanfield_inputs(g, case)
+    for mode in "OX":
+        for n in (200, 2000):
+            want = g[f"nanfield_{case}_{mode}_{n}_vh"]
+            got = lib.vertical_forward_operator(*a, mode, n)
+            assert_masks(got, want)
+            if not np.isfinite(want).any():
+                continue
+            if mode == "X":
+                assert_x_mode(got, want)
+            else:
+                assert_o_mode(got, want, oracle_noise(*a, "O", n, runs=8, seed=n))

@@ -222,3 +222,19 @@ def test_tall_and_nan_padded_profiles_g13():
         assert np.array_equal(np.isnan(got), np.isnan(want))
         ok = np.isfinite(want)
         assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 1e-12
+
+
+def test_nan_in_alt_bmag_bpsi_g13():
+    """The reference's behaviour for a NaN in the altitude, field-strength or field-angle column (fixture G13
+    `nanfield`: whole trace NaN, or the sum skips the blanked grid points)."""
+    g = load_golden("g13_tall_nanpad.npz")
+    day = load_golden("g4_day_night.npz")
+    for case in g["nanfield_cases"]:
+        a = {"den": day["Day_den"].copy(), "bmag": day["Day_bmag"].copy(), "bpsi": day["Day_bpsi"].copy(),
+             "alt": day["Day_alt"].copy()}
+        a[str(g[f"nanfield_{case}_col"])][g[f"nanfield_{case}_levels"]] = np.nan
+        for mode in "OX":
+            for n in (200, 2000):
+                with np.errstate(all="ignore"):
+                    got = orc.virtual_heights(g["nanpad_freq"], a["den"], a["bmag"], a["bpsi"], a["alt"], mode, n)
+                assert same_bits(got, g[f"nanfield_{case}_{mode}_{n}_vh"]), (case, mode, n)

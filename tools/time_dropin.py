@@ -1,6 +1,6 @@
 """Latency of the drop-in call as a PyRayHF user makes it: NumPy arrays in, NumPy array out, one profile."""
 import sys, os, json, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyrayhf_amd import library, synth
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
