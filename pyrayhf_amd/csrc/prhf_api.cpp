@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <xmmintrin.h>
 
 #include "prhf.h"
 #include "prhf_kernels.h"
@@ -40,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr size_t kPackBytes = 1u << 20;
+constexpr size_t kDirectBytes = 128u << 10;   // inputs up to this size are written by the CPU through the BAR (direct_upload)
 
 // Launch-shaping and arithmetic settings of one context (prhf_ctx_set_option).  The defaults are
 // the measured best; tests and A/B runs change them per context.  Only a -DPRHF_DIAG build reads them from the
@@ -59,6 +61,8 @@ struct Knobs {
     double shortx_kernel = 1;          // 0: X-mode grids of up to 4096 points stay in the general kernel
     double short_concurrent = 1;       // 0: short-grid and general launch of a mixed list one after the other
     double short_queue = 0;            // > 0: the short-grid kernel's queue holds exactly this many entries (tests)
+    double direct_upload = 1;          // small host-buffer calls on a large-BAR device: the CPU writes the inputs straight into
+                                       // device memory (0: pinned staging buffer + hipMemcpyAsync)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -83,6 +87,7 @@ const KnobName kKnobNames[] = {
     {"short_concurrent", &Knobs::short_concurrent, 0, 1},
     {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
     {"local_chunks", &Knobs::local_chunks, 0, 1},
+    {"direct_upload", &Knobs::direct_upload, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -153,6 +158,7 @@ struct prhf_ctx {
     int math = PRHF_MATH_AUTO;
     Knobs knobs;
     int cu_count = 256;
+    int large_bar = 0;   // hipDeviceAttributeIsLargeBar: device memory is mapped into the host's address space
     DevBuf arena;     // staged host inputs + output
     DevBuf partial;   // chunk sums
     DevBuf altmin;    // per-profile min(alt) for chunked slices
@@ -516,7 +522,19 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             // buffer and send them in one piece.  The buffer is reused by the next call, so the copy must
             // have left it first: the previous call has synchronised unless it was asynchronous, which host
             // buffers never are.
-            double* h = c->h_pack;
+            // On a large-BAR device (every Instinct board) the staging buffer is not needed either: device memory is
+            // mapped into this process, so the CPU writes the 22 KB of a single-profile call straight into the arena -
+            // posted write-combined stores over PCIe, 0.4 - 0.8 us (tools/probes/bar_probe.cpp) - and the copy kernel
+            // the runtime would have launched for the upload, with its dependency in front of ours (~10 us between
+            // them), is gone.  Ordering: the stores are fenced before the launch's doorbell write, which travels the same
+            // way behind them; the kernel's start-of-kernel acquire drops what its L2 still holds of the arena.  The arena
+            // must be idle: host-buffer calls synchronise before they return, but an asynchronous device-pointer call -
+            // or a launch on a stream the context borrowed before - may still be using it; then the staged copy, which is
+            // ordered by the stream, is taken.
+            bool direct = c->large_bar && kn.direct_upload != 0 && in_elems * 8 <= kDirectBytes &&
+                          hipStreamQuery(c->stream) == hipSuccess && (!c->timed || hipEventQuery(c->end_ev()) == hipSuccess);
+            (void)hipGetLastError();               // (hipErrorNotReady from the two queries is not an error)
+            double* h = direct ? base : c->h_pack;
             std::memcpy(h + (d_freq - base), freq, (size_t)n_freq * 8);
             for (int64_t p = 0; p < n_prof; ++p) {
                 std::memcpy(h + (d_den - base) + (size_t)p * n_alt, den + (size_t)p * prof_stride, row_bytes);
@@ -528,7 +546,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             }
             if (!alt_stride) std::memcpy(h + (d_alt - base), alt, row_bytes);
             if (!grid) std::memcpy(h + (d_mult - base), mult, (size_t)mult_len * 8);
-            HIP_TRY(hipMemcpyAsync(base, h, in_elems * 8, hipMemcpyHostToDevice, c->stream));
+            if (direct) _mm_sfence();
+            else HIP_TRY(hipMemcpyAsync(base, h, in_elems * 8, hipMemcpyHostToDevice, c->stream));
         } else {
             HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->stream));
             if (!grid) HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)mult_len * 8, hipMemcpyHostToDevice, c->stream));
@@ -831,6 +850,7 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
     }
 #endif
     (void)hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, device);
+    if (hipDeviceGetAttribute(&c->large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) c->large_bar = 0;
     if (c->cu_count < 1) c->cu_count = 256;
     *out = c;
     return PRHF_OK;

@@ -19,6 +19,12 @@
 #ifndef PRHF_BLOCK_THREADS
 #define PRHF_BLOCK_THREADS 512      // 8 wavefronts share one staged profile
 #endif
+#ifndef PRHF_SHORT_THREADS
+#define PRHF_SHORT_THREADS 512      // workgroup of the short-grid kernels (vfo_short_kernel, vfo_shortx_kernel)
+#endif
+#ifndef PRHF_SHORT_WAVES_PER_SIMD
+#define PRHF_SHORT_WAVES_PER_SIMD 4 // ... and the occupancy their register budget is set for
+#endif
 #define PRHF_HINT_BUCKETS 1024      // uint16 segment hints, 2 KiB of LDS (non-uniform altitude grids)
 #define PRHF_MAX_CAND 1024          // uint16 list of the frequencies that may reflect, 2 KiB of LDS
 #define PRHF_MAX_SEGMENTS 8
@@ -120,7 +126,7 @@ inline size_t tall_slab_bytes(long long n_alt) {
 // LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
 // nodes, then `queue` entries of 8 bytes (a profile with K < n_alt levels adds its unused nodes to the queue).
 inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq) {
-    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_BLOCK_THREADS / 64) * 16 * 12 +
+    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_SHORT_THREADS / 64) * 16 * 12 +
                      PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 4 + (size_t)n_freq * 2;
     return (b + 15) & ~(size_t)15;
 }

@@ -2323,14 +2323,14 @@ hipError_t launch_residual(const double* vh_model, const double* vh_obs, long lo
 #include "prhf_short.inc"
 
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
-    constexpr int THREADS = PRHF_BLOCK_THREADS;
+    constexpr int THREADS = PRHF_SHORT_THREADS;
     if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL((vfo_short_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
-    constexpr int THREADS = PRHF_BLOCK_THREADS;
+    constexpr int THREADS = PRHF_SHORT_THREADS;
     if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL((vfo_shortx_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
     return hipGetLastError();
@@ -2353,8 +2353,8 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
     const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
-                             reinterpret_cast<const void*>(&vfo_short_kernel<THREADS>),
-                             reinterpret_cast<const void*>(&vfo_shortx_kernel<THREADS>),
+                             reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS>),
+                             reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_SHORT_THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);

@@ -17,6 +17,8 @@ grid) are provided under the reference's names so that callers can switch import
 
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 
 from . import _native, logger
@@ -202,6 +204,27 @@ def _as_rows(name, x):
     return a
 
 
+_ptr_cache = {}
+
+
+def _ptr(x):
+    """Address of a C-contiguous float64 array.  ``x.ctypes.data`` builds a ctypes object per access (~1 us): a
+    sweep calls the operator with the same ``freq``, ``alt``, ``bmag``, ``bpsi`` arrays again and again, so the address
+    is remembered per array object (weak reference: an id that was recycled for another array does not match)."""
+    key = id(x)
+    hit = _ptr_cache.get(key)
+    if hit is not None and hit[0]() is x and hit[2] == x.size:      # (size: a forced in-place resize moves the data)
+        return hit[1]
+    p = x.ctypes.data
+    try:
+        if len(_ptr_cache) > 64:
+            _ptr_cache.clear()
+        _ptr_cache[key] = (weakref.ref(x), p, x.size)
+    except TypeError:                                # (an ndarray subclass without weak references)
+        pass
+    return p
+
+
 def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     if type(freq) is np.ndarray and freq.ndim == 1 and freq.dtype == np.float64 and freq.flags.c_contiguous:
         f = freq
@@ -227,8 +250,9 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     out = np.empty((n_prof, f.size), dtype=np.float64)
     ctx = _native.host_context(device)
     ctx.set_math(_default_math(mode_code, math))
-    rc = ctx.vfo_batch(f.ctypes.data, f.size, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data,
-                       n_prof, n_alt, n_alt, alt_stride, mult.ctypes.data, int(n_points), mode_code,
+    # (d, b, p: the caller's own array objects - their reshaped views share the address)
+    rc = ctx.vfo_batch(_ptr(f), f.size, _ptr(d), _ptr(b), _ptr(p), _ptr(a),
+                       n_prof, n_alt, n_alt, alt_stride, _ptr(mult), int(n_points), mode_code,
                        out.ctypes.data, (_native.FLAG_SHARED_FIELD if shared else 0) | _grid_flag(mult, n_points))
     _native.raise_for(rc)
     return out[0] if single else out

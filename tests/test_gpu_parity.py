@@ -701,3 +701,31 @@ def test_nan_in_altitude_field_strength_or_angle_behaves_as_in_the_reference_g13
                 assert_x_mode(got, want)
             else:
                 assert_o_mode(got, want, oracle_noise(*a, "O", n, runs=8, seed=n))
+
+
+def test_inputs_written_through_the_bar_are_never_stale(lib):
+    """Small host-buffer calls write their inputs straight into device memory from the CPU (large BAR, option
+    direct_upload).  Nothing orders those stores but the launch that follows them, and the GPU's caches are not
+    snooped: alternate between profiles, frequencies sweeps and grid sizes a few hundred times and require every
+    result to be bit-identical to what the staged upload (direct_upload = 0) gives for the same inputs."""
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(6, 4242)
+    sweeps = [synth.sounder_frequencies(1), np.linspace(1.0, 9.0, 40), np.linspace(2.0, 12.0, 174)]
+    cases = [(p, k, mode, n) for p in range(6) for k in range(3) for mode, n in (("O", 200), ("X", 200), ("X", 2000))]
+    lib.set_option("direct_upload", 0)
+    try:
+        want = [lib.vertical_forward_operator(sweeps[k], den[p], bmag[p], bpsi[p], alt, mode, n) for p, k, mode, n in cases]
+    finally:
+        lib.set_option("direct_upload", 1)
+    rng = np.random.default_rng(7)
+    for it in range(400):
+        i = int(rng.integers(len(cases)))
+        p, k, mode, n = cases[i]
+        got = lib.vertical_forward_operator(sweeps[k], den[p], bmag[p], bpsi[p], alt, mode, n)
+        assert np.array_equal(got, want[i], equal_nan=True), (it, cases[i])
+    # a 2-row batch and a call whose inputs exceed the direct limit in between
+    big = lib.vertical_forward_operator(sweeps[2], den, bmag, bpsi, alt, "X", 200)
+    for i in (0, 17, 33):
+        p, k, mode, n = cases[i]
+        assert np.array_equal(lib.vertical_forward_operator(sweeps[k], den[p], bmag[p], bpsi[p], alt, mode, n), want[i], equal_nan=True)
+    assert np.array_equal(big[2], lib.vertical_forward_operator(sweeps[2], den[2], bmag[2], bpsi[2], alt, "X", 200), equal_nan=True)
