@@ -598,10 +598,11 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         neg |= (d < 0.0) ? 1 : 0;
         neg |= (b != b) ? 2 : 0;                   // NaN in |B| below the peak
         neg |= (p != p) ? 4 : 0;                   // ... in psi
+        neg |= (b == b) ? 8 : 0;                   // some |B| below the peak is a number
     }
     bmax = wave_max(bmax);
     pmax = wave_max(pmax);
-    neg = (__any(neg & 1) ? 1 : 0) | (__any(neg & 2) ? 2 : 0) | (__any(neg & 4) ? 4 : 0);
+    neg = (__any(neg & 1) ? 1 : 0) | (__any(neg & 2) ? 2 : 0) | (__any(neg & 4) ? 4 : 0) | (__any(neg & 8) ? 8 : 0);
     ragged = __any(ragged) ? 1 : 0;
     // 5: some segment turns the field by more than kTrigAngle (sin() per point, generic loop), 1: some segment needs the
     // rotation form, 2: some segment keeps its cubic, 3: some keeps its quadratic, 0: all linear
@@ -643,7 +644,9 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
-    info.unmag = ((kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
+    // (np.nanmax of nothing but NaN is NaN, which is not below the tolerance: a |B| column that is NaN at every level
+    //  below the peak stays on the magnetised formulas - and gives NaN everywhere, as in the reference)
+    info.unmag = ((neg & 8) && (kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
     info.poly_angle = trig == 5 ? 0 : (trig == 1 ? 4 : (trig == 2 ? 1 : (trig == 3 ? 2 : 3)));
     if (info.poly_angle == 4) {
         // Rotation form for EVERY segment of this profile: 2 cos^2(psi_j + r x) = 1 + cos(2 psi_j) cos(theta) -

@@ -729,3 +729,16 @@ def test_inputs_written_through_the_bar_are_never_stale(lib):
         p, k, mode, n = cases[i]
         assert np.array_equal(lib.vertical_forward_operator(sweeps[k], den[p], bmag[p], bpsi[p], alt, mode, n), want[i], equal_nan=True)
     assert np.array_equal(big[2], lib.vertical_forward_operator(sweeps[2], den[2], bmag[2], bpsi[2], alt, "X", 200), equal_nan=True)
+
+
+def test_field_strength_that_is_nan_everywhere_gives_nan_as_in_the_reference(lib):
+    """np.nanmax of an all-NaN |Y| array is NaN, which is not below the isotropic tolerance (library.py:201): the
+    magnetised formulas run on NaN and every virtual height is NaN - not the isotropic answer."""
+    from oracle import vfo_numpy as orc
+    g = load_golden("g4_day_night.npz")
+    b = np.full_like(g["Day_bmag"], np.nan)
+    for mode in "OX":
+        with np.errstate(all="ignore"):
+            want = orc.virtual_heights(g["freq"], g["Day_den"], b, g["Day_bpsi"], g["Day_alt"], mode, 200)
+        got = lib.vertical_forward_operator(g["freq"], g["Day_den"], b, g["Day_bpsi"], g["Day_alt"], mode, 200)
+        assert not np.isfinite(want).any() and np.array_equal(np.isnan(got), np.isnan(want)), mode
