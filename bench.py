@@ -497,6 +497,22 @@ def main():
                                         "ms_per_call": 1e3 * dt1, "integrals_per_s": f1.size / dt1,
                                         "kernel_ms": ctx.last_kernel_ms()}
 
+        if world == 1 and not args.no_single_profile:
+            # BASELINE configs[0] and configs[1] as a PyRayHF user makes the call: one profile, NumPy arrays in,
+            # a NumPy array out (wall time per call; inputs in host memory - a latency, never `value`)
+            f1 = synth.sounder_frequencies(1)
+            one = [np.ascontiguousarray(x) for x in (den[0], bmag[0], bpsi[0], alt)]
+            legs = {}
+            for name, (m1, n1) in (("config1_O_200", ("O", 200)), ("config2_X_20000", ("X", 20000))):
+                for _ in range(5):
+                    library.vertical_forward_operator(f1, *one, m1, n1)
+                reps, t1 = 100, time.perf_counter()
+                for _ in range(reps):
+                    library.vertical_forward_operator(f1, *one, m1, n1)
+                legs[name] = {"us_per_call": 1e6 * (time.perf_counter() - t1) / reps, "kernel_us": 1e3 * ctx.last_kernel_ms()}
+            result["dropin_call"] = dict(legs, workload="configs[0] / configs[1]: 1 profile x 174 freqs through "
+                                         "vertical_forward_operator on NumPy arrays (host buffers in and out)")
+
         if world == 1 and not args.no_single_profile and local_segs is None:
             # the same batch handed over as host NumPy buffers (pageable): H2D + kernel + D2H
             # first call: the library's staging arena grows to this batch (hipMalloc); second call: steady state
