@@ -509,7 +509,7 @@ def main():
                 reps, t1 = 100, time.perf_counter()
                 for _ in range(reps):
                     library.vertical_forward_operator(f1, *one, m1, n1)
-                legs[name] = {"us_per_call": 1e6 * (time.perf_counter() - t1) / reps, "kernel_us": 1e3 * ctx.last_kernel_ms()}
+                legs[name] = {"us_per_call": 1e6 * (time.perf_counter() - t1) / reps}
             result["dropin_call"] = dict(legs, workload="configs[0] / configs[1]: 1 profile x 174 freqs through "
                                          "vertical_forward_operator on NumPy arrays (host buffers in and out)")
 

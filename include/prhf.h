@@ -276,8 +276,10 @@ int prhf_occupancy(prhf_ctx* ctx, int64_t n_alt, int32_t math, int32_t* workgrou
  * kernel flagged bad input since the last sync. */
 int prhf_sync(prhf_ctx* ctx);
 
-/* Device time of the most recent launch (all kernels of that call), from HIP events on the
- * context's stream.  Synchronises on the stop event. */
+/* Device time of the most recent TIMED launch (all kernels of that call), from HIP events on the
+ * context's stream.  Synchronises on the stop event.  Every launch on device pointers is timed; a synchronous
+ * host-buffer call of the operator (prhf_vfo_batch_f64 / _worklist / _residual without PRHF_FLAG_DEVICE_PTRS) is
+ * timed only after prhf_ctx_set_option(ctx, "timing", 1): its two event records are 3.5 us of a 41 us call. */
 int prhf_last_kernel_ms(prhf_ctx* ctx, double* ms);
 
 /* The same for the most recent launches, oldest first: at most `capacity` of them (the context remembers 64);

@@ -63,6 +63,10 @@ struct Knobs {
     double short_queue = 0;            // > 0: the short-grid kernel's queue holds exactly this many entries (tests)
     double direct_upload = 1;          // small host-buffer calls on a large-BAR device: the CPU writes the inputs straight into
                                        // device memory (0: pinned staging buffer + hipMemcpyAsync)
+    double timing = 0;                 // 1: synchronous host-buffer operator calls record timing events too (device-pointer
+                                       // launches always do).  Off by default: the two event records cost 3.5 us of a
+                                       // 41 us single-profile call, and nothing is left on the stream when such a call
+                                       // returns; prhf_last_kernel_ms keeps reporting the last launch that was timed
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -88,6 +92,7 @@ const KnobName kKnobNames[] = {
     {"short_queue", &Knobs::short_queue, 0, PRHF_SHORT_MAX_QUEUE},
     {"local_chunks", &Knobs::local_chunks, 0, 1},
     {"direct_upload", &Knobs::direct_upload, 0, 1},
+    {"timing", &Knobs::timing, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -605,7 +610,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         d_cost = post->cost ? p0 + n_freq + out_elems : nullptr;
     }
 
-    HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
+    // (a synchronous host-buffer call may go untimed - option `timing`: nothing is left on the stream when it returns,
+    //  so no later launch or stream switch needs its end event either)
+    const bool timed_launch = dev || kn.timing != 0;
+    if (timed_launch) HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     if (want_pairs && grid) {
         if (!grid->pairs_ready) {
             if ((rc = ensure(c, grid->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
@@ -765,8 +773,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
 #endif
     if (post) HIP_TRY(prhf::launch_residual(vh_dev, d_obs, n_prof, (int)n_freq, d_res, d_cost, c->stream));
-    HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
-    c->mark_timed();
+    if (timed_launch) {
+        HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
+        c->mark_timed();
+    }
     c->status_pending = true;
 
     // small results come back through the pinned buffer too (its upper half; the inputs of a call this small

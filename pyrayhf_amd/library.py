@@ -450,7 +450,9 @@ def set_option(name, value, device=None):
 
 
 def last_kernel_ms(device=None):
-    """Device time [ms] of the most recent launch on this thread's context."""
+    """Device time [ms] of the most recent TIMED launch on this thread's context: every launch on GPU-resident
+    inputs, and calls on NumPy arrays after ``set_option("timing", 1)`` (off by default: the two event records are
+    3.5 us of a 41 us single-profile call)."""
     return _native.context(device).last_kernel_ms()
 
 

@@ -132,3 +132,27 @@ def test_recent_kernel_ms_reports_every_launch_of_an_unsynchronised_series():
         library.vertical_forward_operator(t["freq"], t["den"], t["bmag"], t["bpsi"], t["alt"], "X", 200, sync=False, out=out)
     assert len(ctx.recent_kernel_ms(1000)) == 64
     assert library.recent_kernel_ms(3) == ctx.recent_kernel_ms(3)
+
+
+def test_host_buffer_calls_are_timed_on_request_only():
+    """Option `timing`: a synchronous host-buffer call records its two timing events only when asked to;
+    launches on device pointers always do."""
+    import torch
+    from pyrayhf_amd import _native, library, synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(2, 3)
+    freq = synth.sounder_frequencies(1)
+    ctx = _native.Context(0)                      # a fresh context: nothing timed yet
+    try:
+        out = np.empty((1, freq.size))
+        m = np.ascontiguousarray(library.smooth_nonuniform_grid(0, 1, 200, 10.0))
+        args = (freq.ctypes.data, freq.size, den[0].ctypes.data, bmag[0].ctypes.data, bpsi[0].ctypes.data, alt.ctypes.data,
+                1, alt.size, alt.size, 0, m.ctypes.data, 200, _native.MODE_X, out.ctypes.data, 0)
+        _native.raise_for(ctx.vfo_batch(*args))
+        with pytest.raises(Exception, match="no launch has been timed"):
+            ctx.last_kernel_ms()
+        ctx.set_option("timing", 1)
+        untimed = out.copy()
+        _native.raise_for(ctx.vfo_batch(*args))
+        assert 0.0 < ctx.last_kernel_ms() < 5.0 and np.array_equal(out, untimed, equal_nan=True)
+    finally:
+        ctx.close()
