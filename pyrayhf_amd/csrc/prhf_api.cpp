@@ -188,7 +188,8 @@ struct prhf_ctx {
     HostGrid host_grid[kHostGrids];
     int n_host_grids = 0;
     unsigned* d_status = nullptr;   // device words [1..5]: block queues of persistent launches (general, short-grid O and its
-                                    // follow-up, short-grid X and its follow-up); [0] unused
+                                    // follow-up, short-grid X and its follow-up); [6]: ray queue of the per-ray tracer launch;
+                                    // [0] unused
     unsigned* h_status = nullptr;   // PRHF_STATUS_WORDS words of pinned host memory mapped into the device: word b = status
     unsigned* h_status_dev = nullptr;   // bit b (post_status) - nothing to copy back or reset on the device; its device address
     double* h_pack = nullptr;       // pinned, kPackBytes: inputs of a small host-buffer call, sent in one piece; its upper
@@ -1249,7 +1250,15 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         a.levels = static_cast<double*>(c->levels.p);
     } else {
         a.freq_hz = d_keyf; a.prof_idx = d_keyp;
+        // per-ray launch: one slab of mu / mu' per resident wavefront (the level table's buffer is free here)
+        long long waves = 0;
+        HIP_TRY(prhf::snell_resident_waves(n_alt, c->cu_count, &waves));
+        int rc3 = ensure(c, c->levels, (size_t)waves * 2 * (size_t)(n_alt + 1) * 8);
+        if (rc3 != PRHF_OK) return rc3;
+        a.ray_scratch = static_cast<double*>(c->levels.p);
+        a.ray_queue = c->d_status + 6;
     }
+    a.resident_cus = c->cu_count;
     {
         int rc2 = ensure(c, c->partial, (size_t)n_prof * 16);      // per-profile scalars (the operator's chunk scratch is free here)
         if (rc2 != PRHF_OK) return rc2;
