@@ -136,9 +136,10 @@ int prhf_ctx_set_option(prhf_ctx* ctx, const char* name, double value);
  *   makes the profile's row NaN (:507), and so does a NaN in bmag below the peak in X mode (:389); in O mode, and for
  *   a NaN in bpsi, the grid points of the two segments next to that level drop out of the sum (:288).
  *   (prhf_regrid_f64 refuses a NaN in alt, or in bmag / bpsi below the peak: PRHF_EINVAL.)
- * Limits: n_alt <= 65535, n_freq <= 2^20, n_points >= 1.  Up to 1400 levels a profile's bottomside is held in LDS;
- * taller profiles are staged in global memory (one slab per resident workgroup, allocated by the context) and
- * take the generic loop - same values, about three times the time per grid point.
+ * Limits: n_alt <= 65535, n_freq <= 2^20, n_points >= 1.  A profile's bottomside - the levels below its density
+ * peak - is held in LDS when it has at most 1400 levels (for n_alt > 1400 a pre-pass finds the highest peak of the
+ * launch: one synchronisation); taller bottomsides are staged in global memory (one slab per resident workgroup,
+ * allocated by the context) and take the generic loop - same values, about three times the time per grid point.
  */
 int prhf_vfo_batch_f64(prhf_ctx* ctx,
                        const double* freq_mhz, int64_t n_freq,

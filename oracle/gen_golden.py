@@ -462,6 +462,7 @@ def gen_tall(lib):
     """G13.  Profiles of more levels than the kernel keeps in LDS (the reference has no limit, library.py:371-375)
     and densities padded with NaN (np.argmax returns the first NaN, :371: the padding acts as the peak).
       tall_day   the Day example resampled to 0.2 km (3 096 levels), 174 freqs: O/200 with its noise floor, X/2000
+      tall_fine  the Day example at 0.1 km (6 191 levels, peak at level 2 580), 34 freqs: O/200, X/2000
       tall_rag   a Chapman layer on 2 600 levels with irregular spacing (0.05 - 0.45 km), 96 freqs: O/200, X/500
       nanpad     the Day example with den = NaN from level 300 up (above the peak at 258) and from level 200 up
                  (below it: the layer is cut short), 174 freqs, O/200 and X/200
@@ -478,6 +479,15 @@ def gen_tall(lib):
     g["tall_day_O_200_vh"], g["tall_day_O_200_noise"] = noise_floor(lib, freq, tall["den"], tall["bmag"], tall["bpsi"],
                                                                     alt, "O", 200, seed=1301)
     g["tall_day_X_2000_vh"] = lib.vertical_forward_operator(freq, tall["den"], tall["bmag"], tall["bpsi"], alt, "X", 2000)
+    # ... and at 0.1 km (6 191 levels): its peak sits at level 2 580 - not even the bottomside fits LDS (1 400 levels)
+    alt_f = np.arange(d["alt"][0], d["alt"][-1] + 1e-9, 0.1)
+    fine = {k: np.interp(alt_f, d["alt"], d[k]) for k in ("den", "bmag", "bpsi")}
+    freq_f = np.arange(0.5, 17.5, 0.5)
+    g.update(tall_fine_freq=freq_f, tall_fine_alt=alt_f, tall_fine_den=fine["den"], tall_fine_bmag=fine["bmag"],
+             tall_fine_bpsi=fine["bpsi"])
+    g["tall_fine_O_200_vh"], g["tall_fine_O_200_noise"] = noise_floor(lib, freq_f, fine["den"], fine["bmag"], fine["bpsi"],
+                                                                      alt_f, "O", 200, seed=1305)
+    g["tall_fine_X_2000_vh"] = lib.vertical_forward_operator(freq_f, fine["den"], fine["bmag"], fine["bpsi"], alt_f, "X", 2000)
     rng = np.random.default_rng(1302)
     alt_r = 80.0 + np.concatenate(([0.0], np.cumsum(rng.uniform(0.05, 0.45, size=2599))))
     a1, den1, bmag1, bpsi1 = synth.chapman_profiles(4, 1302, rows=slice(2, 3))

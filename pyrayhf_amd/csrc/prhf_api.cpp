@@ -67,6 +67,8 @@ struct Knobs {
                                        // launches always do).  Off by default: the two event records cost 3.5 us of a
                                        // 41 us single-profile call, and nothing is left on the stream when such a call
                                        // returns; prhf_last_kernel_ms keeps reporting the last launch that was timed
+    double trim_lds = 1;               // columns of more than 1400 levels: stage only up to the highest peak of the launch and
+                                       // stay on the LDS kernels when that fits (0: always the global-memory slabs)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -93,6 +95,7 @@ const KnobName kKnobNames[] = {
     {"local_chunks", &Knobs::local_chunks, 0, 1},
     {"direct_upload", &Knobs::direct_upload, 0, 1},
     {"timing", &Knobs::timing, 0, 1},
+    {"trim_lds", &Knobs::trim_lds, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -314,8 +317,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     if (n_alt > kMaxAltTall) return fail(PRHF_EINVAL, "n_alt %lld exceeds the limit of %lld levels",
                                          (long long)n_alt, kMaxAltTall);
     // Profiles of more levels than LDS holds are staged in global memory and take the generic loop (vfo_tall_kernel):
-    // no main loop, no candidate list, no short-grid kernels - the same values as any profile that leaves those paths
-    const bool tall = n_alt > kMaxAlt;
+    // no main loop, no candidate list, no short-grid kernels - the same values as any profile that leaves those paths.
+    // Decided below, once the highest density peak of the launch is known: only the bottomside is staged, and a
+    // column of 2 500 levels at 0.25 km has its peak near level 900.
+    bool tall = n_alt > kMaxAlt;
     if (n_freq > (1 << 20)) return fail(PRHF_EINVAL, "n_freq too large");
     if (prof_stride < n_alt || (alt_stride != 0 && alt_stride < n_alt))
         return fail(PRHF_EINVAL, "row stride shorter than a row");
@@ -344,6 +349,38 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 
     ENTER_DEVICE(c->device);
 
+    // More levels than LDS holds: find the highest peak index of the launch (np.argmax, the first NaN ranking highest -
+    // stage_profile's rule).  When every bottomside fits, the LDS kernels run with their staged arrays sized for that
+    // peak (KArgs::lds_levels) - all of them but the short-grid kernels, whose LDS layout is tied to n_alt.
+    long long lds_levels = n_alt;
+    if (tall && n_prof > 0 && c->knobs.trim_lds != 0) {
+        long long max_peak = 0;
+        if (dev) {
+            HIP_TRY(hipMemsetAsync(c->d_status + 7, 0, sizeof(unsigned), c->stream));
+            HIP_TRY(prhf::launch_peak_levels(den, n_prof, n_alt, prof_stride, c->d_status + 7, c->stream));
+            unsigned peak = 0;
+            HIP_TRY(hipMemcpyAsync(&peak, c->d_status + 7, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            max_peak = peak;
+        } else {
+            for (int64_t p = 0; p < n_prof; ++p) {
+                const double* d = den + (size_t)p * prof_stride;
+                double bv = -HUGE_VAL;
+                long long bi = 0;
+                for (int64_t i = 0; i < n_alt; ++i) {
+                    const double key = (d[i] != d[i]) ? HUGE_VAL : d[i];
+                    if (key > bv) { bv = key; bi = i; }
+                }
+                max_peak = std::max(max_peak, bi);
+            }
+        }
+        if (max_peak + 1 <= kMaxAlt) {
+            tall = false;
+            lds_levels = max_peak + 1;
+        }
+    }
+    const bool lds_trimmed = lds_levels != n_alt;
+
     const Knobs& kn = c->knobs;
     const double kWellConditioned = kn.well_conditioned, kThreadScanMinWork = kn.thread_scan_min;
     const int kLeanMinPoints = (int)kn.lean_min_points, kNoCandidates = kn.no_candidates != 0;
@@ -355,6 +392,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     std::memset(&a, 0, sizeof a);
     a.n_freq = n_freq;
     a.n_alt = n_alt;
+    a.lds_levels = lds_levels;
     a.n_segs = n_segs;
     // Slices of short O-mode grids leave for a launch of their own (vfo_short_kernel): `a` keeps the others
     prhf::SegDev short_seg[PRHF_MAX_SEGMENTS], shortx_seg[PRHF_MAX_SEGMENTS];
@@ -368,7 +406,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     int launch_tier = 0;
     bool want_pairs = false;
     // resident workgroups: LDS admits two per CU up to 80 KiB each, else one
-    const long long wg_slots = (long long)c->cu_count * ((tall || prhf::lds_bytes_for(n_alt) <= 80 * 1024) ? 2 : 1);
+    const long long wg_slots = (long long)c->cu_count * ((tall || prhf::lds_bytes_for(lds_levels) <= 80 * 1024) ? 2 : 1);
     for (int i = 0; i < n_segs; ++i) {
         const prhf_segment& u = segs[i];
         if (u.prof_begin < 0 || u.prof_end < u.prof_begin || u.prof_end > n_prof)
@@ -420,7 +458,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             // (grids shorter than the general kernel's main loop takes - lean_min_points - are theirs too: the pair
             //  table is built for them)
             const long long slice_pairs = (s.prof_end - s.prof_begin) * n_freq;
-            const bool table = !tall && (s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints));
+            const bool table = !tall && !lds_trimmed && (s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints));
             const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && table && s.chunks == 1 &&
                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
                                   n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && short_queue > 0;
@@ -676,7 +714,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             grid_blocks = wg_slots;
         }
         if (tall) HIP_TRY(prhf::launch_vfo_tall(a, grid_blocks, c->stream));
-        else HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(n_alt), c->stream));
+        else HIP_TRY(prhf::launch_vfo(a, grid_blocks, launch_tier, prhf::lds_bytes_for(lds_levels), c->stream));
         return PRHF_OK;
     };
     const bool any_short = n_short > 0 || n_shortx > 0;

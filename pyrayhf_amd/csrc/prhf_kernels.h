@@ -106,6 +106,9 @@ struct KArgs {
     // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
     unsigned char* tall;
     unsigned long long tall_stride;
+    // Levels the staged arrays (nodes, f_N^2, g_p |B|) have room for: n_alt, or - a column of more than 1400 levels
+    // whose bottomsides all fit LDS (launch_peak_levels) - the highest peak index of the launch + 1
+    long long lds_levels;
     SegDev seg[PRHF_MAX_SEGMENTS];
 };
 
@@ -162,6 +165,11 @@ hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* t
 hipError_t launch_vfo(const KArgs& a, long long grid_blocks, int tier, size_t lds_bytes, hipStream_t stream);
 // profiles of more than 1400 levels: a.tall holds grid_blocks slabs of a.tall_stride >= tall_slab_bytes(n_alt) bytes
 hipError_t launch_vfo_tall(const KArgs& a, long long grid_blocks, hipStream_t stream);
+// *max_peak (one device word, zeroed by the caller) = the highest density-peak index - np.argmax, the first NaN
+// ranking highest, exactly stage_profile's rule - over n_prof profiles: a column of more levels than LDS holds can
+// still take the LDS kernels when every bottomside fits
+hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_alt, long long prof_stride,
+                              unsigned* max_peak, hipStream_t stream);
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);

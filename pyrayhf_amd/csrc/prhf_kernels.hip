@@ -420,7 +420,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                                                    const double* __restrict__ alt,
                                                    const double* __restrict__ freq, int n_freq,
                                                    int n_alt, Node* nodes, double* pf2, double* gb,
-                                                   unsigned short* hint, double* red) {
+                                                   unsigned short* hint, double* red, int capacity) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
     static_assert(10 * W + 3 <= PRHF_RED_DOUBLES, "reduction scratch too small");
@@ -514,6 +514,11 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     }
     if (K == 0) {
         info.bad = PRHF_STATUS_PEAK0;
+        return info;
+    }
+    if (K >= capacity) {                           // cannot happen: the host sized the staged arrays for the highest
+        info.bad = PRHF_STATUS_BADINDEX;           // peak of the launch (launch_peak_levels: the same argmax rule) -
+        info.K = 0;                                // but an overrun of LDS must not be what tells us otherwise
         return info;
     }
     // ---- phase 2: nodes (values, np.interp slopes), f_N^2, g_p B, and the per-profile flags ------
@@ -1740,7 +1745,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     const long long p = sg.prof_begin + prof_local;
     BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.field_stride, a.bpsi + p * a.field_stride,
-        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red);
+        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red, (int)a.lds_levels);
     PRHF_MARK(1);
     if (sg.mode == PRHF_KMODE_X && info.nan_b && !info.bad) info.bad = kNanRow;     // (see stage_profile)
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
@@ -1752,7 +1757,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         // Reflection heights settled while the list is made live where the level search kept its input: O mode
         // never reads g_p |B| per level again; X mode (one round of frequencies only) reads neither array again
         double* heights = nullptr;
-        if (a.n_freq <= a.n_alt) {
+        if (a.n_freq <= a.lds_levels) {
             if (sg.mode == PRHF_KMODE_O) heights = gb;
             else if (a.n_freq <= THREADS && sg.thread_scan) heights = pf2;
         }
@@ -1789,7 +1794,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
 template <int TIER_SEL, int THREADS, bool TALL>
 __device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_alt = (int)a.n_alt;
+    const int n_alt = (int)a.lds_levels;               // (room of the staged arrays: a.n_alt unless the host knows better)
     Node* nodes;
     double* pf2;
     unsigned short* hint;
@@ -1957,6 +1962,38 @@ __global__ void freq_min_kernel(const double* __restrict__ freq_mhz, long long n
         row[0] = fmin(fmin(part[0], part[1]), fmin(part[2], part[3]));
         for (int k = 1; k < 8; ++k) row[k] = 0.0;
     }
+}
+
+// One wavefront per profile: first-occurrence argmax of the density column, a NaN ranking above every number
+// (stage_profile's phase 1, library.py:371); the launch's maximum goes to *max_peak.
+__global__ __launch_bounds__(256) void peak_levels_kernel(const double* __restrict__ den, long long n_prof, long long n_alt,
+                                                          long long prof_stride, unsigned* __restrict__ max_peak) {
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= n_prof) return;
+    const double* d = den + p * prof_stride;
+    double bv = -__builtin_inf();
+    int bi = 0x7fffffff;
+    for (int i = lane; i < (int)n_alt; i += 64) {
+        const double v = d[i];
+        const double key = (v != v) ? __builtin_inf() : v;
+        if (key > bv) { bv = key; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0 && bi != 0x7fffffff) atomicMax(max_peak, (unsigned)bi);
+}
+
+hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_alt, long long prof_stride,
+                              unsigned* max_peak, hipStream_t stream) {
+    if (n_prof <= 0) return hipSuccess;
+    hipLaunchKernelGGL(peak_levels_kernel, dim3((unsigned)((n_prof + 3) / 4)), dim3(256), 0, stream, den, n_prof, n_alt,
+                       prof_stride, max_peak);
+    return hipGetLastError();
 }
 
 hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream) {
@@ -2217,7 +2254,7 @@ __global__ __launch_bounds__(THREADS) void regrid_kernel(const RegridArgs a) {
     const int lane = threadIdx.x & 63;
     const double one_mhz = 1.0;     // stage_profile only needs a frequency column for the isotropic test
     const BlockInfo info = stage_profile<0, THREADS>(a.den, a.bmag, a.bpsi, a.alt, &one_mhz, 0, n_alt, nodes,
-                                                     pf2, gb, hint, red);
+                                                     pf2, gb, hint, red, n_alt + 1);
     // (the standalone regrid keeps refusing NaN profiles: the operator's NaN rules - stage_profile - are about its sums)
     if (threadIdx.x == 0 && (info.bad || info.nan_b || info.nan_p))
         post_status(a.status, (unsigned)((info.bad & ~kNanRow) | ((info.bad & kNanRow) || info.nan_b || info.nan_p

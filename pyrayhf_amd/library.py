@@ -351,9 +351,9 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     and for a NaN in ``bpsi`` in either mode - the grid points of the two segments next to that level
     drop out of the sum (:288).  A frequency that is not a positive finite number gives NaN for that
     frequency and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for a
-    negative frequency).  Profiles of more than 1400 levels (up to 65 535) are supported but slower:
-    their bottomside does not fit the GPU's local memory and is staged in global memory instead (about
-    three times the time per grid point).
+    negative frequency).  Profiles may have up to 65 535 levels; where the levels BELOW the density
+    peak number more than 1400 they no longer fit the GPU's local memory and are staged in global
+    memory instead (about three times the time per grid point).
     """
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):

@@ -604,15 +604,25 @@ def test_short_grid_kernels_every_shape(lib):
 
 # ---- fixture G13: profiles taller than LDS holds, NaN-padded densities (made by running the reference) ----------
 
-@pytest.mark.parametrize("case,mode,n", [("tall_day", "O", 200), ("tall_day", "X", 2000),
-                                         ("tall_rag", "O", 200), ("tall_rag", "X", 500)])
-def test_profiles_of_more_than_1400_levels_g13(lib, case, mode, n):
-    """The reference has no limit on the number of levels (library.py:371-375).  3 096 / 2 600 levels (uniform /
-    irregular spacing) do not fit LDS: vfo_tall_kernel stages them in global memory."""
+@pytest.mark.parametrize("trim", [1, 0])
+@pytest.mark.parametrize("case,mode,n", [("tall_day", "O", 200), ("tall_day", "X", 2000), ("tall_rag", "O", 200),
+                                         ("tall_rag", "X", 500), ("tall_fine", "O", 200), ("tall_fine", "X", 2000)])
+def test_profiles_of_more_than_1400_levels_g13(lib, case, mode, n, trim):
+    """The reference has no limit on the number of levels (library.py:371-375).  Columns of 3 096 / 2 600 levels
+    (uniform / irregular spacing) do not fit LDS, but their bottomsides (peaks at levels 1 290 / 667) do: staged up to
+    the highest peak of the launch they stay on the LDS kernels (`trim` 1, the default); with `trim_lds` 0 - and always
+    for `tall_fine`, 6 191 levels with the peak at 2 580 - vfo_tall_kernel stages them in global memory."""
     g = load_golden("g13_tall_nanpad.npz")
     a = [g[f"{case}_{k}"] for k in ("freq", "den", "bmag", "bpsi", "alt")]
     assert a[4].size > 1400
-    vh = lib.vertical_forward_operator(*a, mode, n)
+    lib.set_option("trim_lds", trim)
+    try:
+        vh = lib.vertical_forward_operator(*a, mode, n)
+        import torch
+        t = [torch.as_tensor(np.asarray(x, dtype=np.float64), device="cuda:0") for x in a]
+        assert np.array_equal(lib.vertical_forward_operator(*t, mode, n).cpu().numpy(), vh, equal_nan=True)   # (device pre-pass)
+    finally:
+        lib.set_option("trim_lds", 1)
     want = g[f"{case}_{mode}_{n}_vh"]
     if mode == "X":
         print(case, "X", n, "max rel err", assert_x_mode(vh, want))
@@ -631,7 +641,18 @@ def test_tall_profiles_in_batches_and_work_lists(lib):
     alt = np.arange(80.0, 700.0, 0.25)                                    # 2 480 levels
     den, bmag, bpsi = (np.array([np.interp(alt, a0, r) for r in x]) for x in (den0, bmag0, bpsi0))
     freq = np.linspace(1.0, 12.0, 48)
-    for mode, n in (("X", 2000), ("O", 200), ("X", 64)):
+    lib.set_option("trim_lds", 0)                 # (the bottomsides of this batch fit LDS: force the slabs here ...)
+    try:
+        for mode, n in (("X", 2000), ("O", 200), ("X", 64)):
+            got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n)
+            want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n)
+            if mode == "X":
+                assert_x_mode(got, want)
+            else:
+                assert_o_mode(got, want, oracle_noise(freq, den, bmag, bpsi, alt, "O", n, runs=6, seed=5))
+    finally:
+        lib.set_option("trim_lds", 1)
+    for mode, n in (("X", 2000), ("O", 200)):     # (... and the trimmed LDS kernels here)
         got = lib.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n)
         want = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n)
         if mode == "X":

@@ -204,7 +204,8 @@ def test_tall_and_nan_padded_profiles_g13():
     library.py:371), as the reference evaluates them."""
     g = load_golden("g13_tall_nanpad.npz")
     with np.errstate(all="ignore"):
-        for case, runs in (("tall_day", (("O", 200), ("X", 2000))), ("tall_rag", (("O", 200), ("X", 500)))):
+        for case, runs in (("tall_day", (("O", 200), ("X", 2000))), ("tall_rag", (("O", 200), ("X", 500))),
+                           ("tall_fine", (("O", 200), ("X", 2000)))):
             a = [g[f"{case}_{k}"] for k in ("freq", "den", "bmag", "bpsi", "alt")]
             for mode, n in runs:
                 assert same_bits(orc.virtual_heights(*a, mode, n), g[f"{case}_{mode}_{n}_vh"]), (case, mode, n)

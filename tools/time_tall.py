@@ -24,5 +24,9 @@ def run(name, n_alt, mode, n):
 
 for mode, n in (("X", 20000), ("X", 2000), ("O", 200)):
     run("LDS (1400 levels)", 1400, mode, n)
-    run("tall (1401 levels)", 1401, mode, n)
-    run("tall (6200 levels)", 6200, mode, n)
+    run("1401 levels, bottomsides fit LDS (staged up to the highest peak)", 1401, mode, n)
+    run("2480 levels (0.25 km), bottomsides fit LDS", 2480, mode, n)
+    library.set_option("trim_lds", 0)
+    run("1401 levels, global-memory slabs (trim_lds = 0)", 1401, mode, n)
+    library.set_option("trim_lds", 1)
+    run("6200 levels (0.1 km): global-memory slabs", 6200, mode, n)
