@@ -351,7 +351,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 
     // More levels than LDS holds: find the highest peak index of the launch (np.argmax, the first NaN ranking highest -
     // stage_profile's rule).  When every bottomside fits, the LDS kernels run with their staged arrays sized for that
-    // peak (KArgs::lds_levels) - all of them but the short-grid kernels, whose LDS layout is tied to n_alt.
+    // peak (KArgs::lds_levels).
     long long lds_levels = n_alt;
     if (tall && n_prof > 0 && c->knobs.trim_lds != 0) {
         long long max_peak = 0;
@@ -379,7 +379,6 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             lds_levels = max_peak + 1;
         }
     }
-    const bool lds_trimmed = lds_levels != n_alt;
 
     const Knobs& kn = c->knobs;
     const double kWellConditioned = kn.well_conditioned, kThreadScanMinWork = kn.thread_scan_min;
@@ -400,8 +399,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // LDS budget of a short-grid workgroup: two per CU where its nodes allow that, else one (a few hundred bytes of
     // static LDS - tickets, counters - come on top)
     const size_t lds_half = 80 * 1024 - 512, lds_full = 160 * 1024 - 512;
-    const size_t short_budget = prhf::short_queue_entries(n_alt, n_freq, lds_half) ? lds_half : lds_full;
-    const int short_queue = prhf::short_queue_entries(n_alt, n_freq, short_budget);
+    const size_t short_budget = prhf::short_queue_entries(lds_levels, n_freq, lds_half) ? lds_half : lds_full;
+    const int short_queue = prhf::short_queue_entries(lds_levels, n_freq, short_budget);
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
     int launch_tier = 0;
     bool want_pairs = false;
@@ -458,7 +457,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             // (grids shorter than the general kernel's main loop takes - lean_min_points - are theirs too: the pair
             //  table is built for them)
             const long long slice_pairs = (s.prof_end - s.prof_begin) * n_freq;
-            const bool table = !tall && !lds_trimmed && (s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints));
+            const bool table = !tall && (s.lean || (slice_pairs >= 4096 && s.n_points < kLeanMinPoints));
             const bool is_short = kShortKernel && s.tier == 0 && s.well_conditioned < 1.0 && table && s.chunks == 1 &&
                                   s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORT_MAX_POINTS &&
                                   n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && short_queue > 0;
@@ -466,7 +465,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             const bool is_shortx = kShortXKernel && s.tier == 1 && s.mode == PRHF_KMODE_X && table && s.chunks == 1 &&
                                    s.n_points >= PRHF_SHORT_MIN_POINTS && s.n_points <= PRHF_SHORTX_MAX_POINTS &&
                                    n_freq <= PRHF_MAX_CAND && n_prof * n_freq >= 4096 && !kNoCandidates && s.thread_scan &&
-                                   prhf::shortx_lds_bytes(n_alt, n_freq) <= lds_full;
+                                   prhf::shortx_lds_bytes(lds_levels, n_freq) <= lds_full;
             if (is_short || is_shortx) {
                 prhf::SegDev& t = is_short ? short_seg[n_short++] : shortx_seg[n_shortx++];
                 t = s;
@@ -763,8 +762,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if ((rcl = ensure(c, left, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
         as.leftover = static_cast<unsigned*>(left.p);
         HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
-        const size_t lds = xmode ? prhf::shortx_lds_bytes(n_alt, n_freq)
-                                 : prhf::short_lds_fixed(n_alt, n_freq) + 8 * (size_t)short_queue;
+        const size_t lds = xmode ? prhf::shortx_lds_bytes(lds_levels, n_freq)
+                                 : prhf::short_lds_fixed(lds_levels, n_freq) + 8 * (size_t)short_queue;
         const long long short_slots = (long long)c->cu_count * (lds <= lds_half ? 2 : 1);
         long long grid_short = short_blocks;
         if (short_blocks > short_slots) {
@@ -789,7 +788,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         af.block_list = as.leftover;
         af.leftover = nullptr;
         af.queue = c->d_status + (xmode ? 5 : 3);
-        HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), xmode ? 1 : 0, prhf::lds_bytes_for(n_alt), short_stream));
+        HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), xmode ? 1 : 0, prhf::lds_bytes_for(lds_levels), short_stream));
         return PRHF_OK;
     };
     if ((rc = launch_short_kind(true)) != PRHF_OK) return rc;          // (the longer blocks first)
