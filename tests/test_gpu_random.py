@@ -164,3 +164,93 @@ def test_random_batches_on_the_long_launch_paths(seed):
     from random_sweep_batches import check
     checked, bad = check(seed)
     assert bad == 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_problems_with_nan_inputs(seed):
+    """NaN inputs give what the reference gives: the random problems above with NaNs thrown in - a
+    density padded from a random level up, or one to three levels of the altitude, field-strength or field-angle
+    column blanked - against the NumPy oracle, which reproduces the reference's NaN cases of fixture G13 bit for bit."""
+    from oracle import vfo_numpy
+    from pyrayhf_amd import library
+    rng = np.random.default_rng(7000 + seed)
+    checked = 0
+    for _ in range(60):
+        freq, den, bmag, bpsi, alt, n_points = random_problem(rng)
+        if np.any(np.argmax(den, axis=1) == 0):
+            continue
+        alt = np.array(alt, dtype=np.float64, copy=True)
+        n_prof, n_alt = den.shape
+        victim = int(rng.integers(n_prof))
+        what = rng.choice(["den", "alt", "bmag", "bpsi", "bpsi", "bmag"])
+        if what == "den":
+            first = int(rng.integers(1, n_alt))
+            den[victim, first:] = np.nan
+        else:
+            col = {"alt": alt if alt.ndim == 2 else None, "bmag": bmag, "bpsi": bpsi}[what]
+            if col is None:                                     # a shared altitude row: every profile sees the NaN
+                alt[rng.integers(n_alt)] = np.nan
+            else:
+                col[victim, rng.integers(0, n_alt, int(rng.integers(1, 4)))] = np.nan
+        for mode in "XO":
+            with np.errstate(all="ignore"):
+                want = vfo_numpy.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n_points)
+            got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points)
+            assert_masks(got, want)
+            err, ok = rel_err(got, want)
+            if mode == "X":
+                assert err.max(initial=0.0) <= 1e-7, (seed, what, n_points, err.max())
+            else:
+                with np.errstate(all="ignore"):
+                    noise = oracle_noise(freq, den, bmag, bpsi, alt, "O", n_points, runs=12, seed=seed)
+                n_fin = int(np.isfinite(want).sum())
+                try:
+                    assert_o_mode(got, want, noise, max_beyond=max(1, n_fin // 100))
+                except AssertionError as exc:
+                    raise AssertionError(f"seed {seed} NaN in {what}, n_points {n_points}: {exc}") from None
+            checked += 1
+    assert checked > 60
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_tall_columns(seed):
+    """Columns of 1 401 ... 4 000 levels (the random problems above, resampled): staged up to the launch's highest
+    peak when that fits LDS, in global-memory slabs otherwise - and always with `trim_lds` 0 - against the C oracle
+    (X mode) and the NumPy oracle (O mode)."""
+    from oracle import vfo_c, vfo_numpy
+    from pyrayhf_amd import library
+    if not vfo_c.available():
+        pytest.skip("oracle/libvfo_oracle.so not built")
+    rng = np.random.default_rng(8000 + seed)
+    checked = 0
+    for _ in range(14):
+        freq, den, bmag, bpsi, alt, n_points = random_problem(rng)
+        if alt.ndim == 2:
+            alt = alt[0]
+        n_tall = int(rng.integers(1401, 4000))
+        fine = np.linspace(alt[0], alt[-1], n_tall)
+        den, bmag, bpsi = (np.array([np.interp(fine, alt, r) for r in x]) for x in (den, bmag, bpsi))
+        if np.any(np.argmax(den, axis=1) == 0):
+            continue
+        n_points = min(n_points, 777)
+        want_x = vfo_c.virtual_heights_batch(freq, den, bmag, bpsi, fine, "X", n_points)
+        with np.errstate(all="ignore"):
+            want_o = vfo_numpy.virtual_heights_batch(freq, den, bmag, bpsi, fine, "O", n_points)
+            noise = oracle_noise(freq, den, bmag, bpsi, fine, "O", n_points, runs=8, seed=seed)
+        for trim in (1, 0):
+            library.set_option("trim_lds", trim)
+            try:
+                got_x = library.vertical_forward_operator(freq, den, bmag, bpsi, fine, "X", n_points)
+                got_o = library.vertical_forward_operator(freq, den, bmag, bpsi, fine, "O", n_points)
+            finally:
+                library.set_option("trim_lds", 1)
+            assert_masks(got_x, want_x)
+            err, ok = rel_err(got_x, want_x)
+            assert err.max(initial=0.0) <= 1e-7, (seed, trim, n_tall, n_points, err.max())
+            n_fin = int(np.isfinite(want_o).sum())
+            try:
+                assert_o_mode(got_o, want_o, noise, max_beyond=max(1, n_fin // 100))
+            except AssertionError as exc:
+                raise AssertionError(f"seed {seed} trim {trim} levels {n_tall} n_points {n_points}: {exc}") from None
+            checked += 2
+    assert checked > 20
