@@ -603,7 +603,9 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         neg |= (d < 0.0) ? 1 : 0;
         neg |= (b != b) ? 2 : 0;                   // NaN in |B| below the peak
         neg |= (p != p) ? 4 : 0;                   // ... in psi
-        neg |= (b == b) ? 8 : 0;                   // some |B| below the peak is a number
+        // some SAMPLED |B| is a number (np.nanmax over the regridded array, :201): grid point 0 sits on level 0, any
+        // other grid point inside a segment - a number only when both its ends are
+        neg |= ((k == 0 && b == b) || (k + 1 < K && b == b && bmag[k + 1] == bmag[k + 1])) ? 8 : 0;
     }
     bmax = wave_max(bmax);
     pmax = wave_max(pmax);
@@ -649,8 +651,9 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // library.py:201: nanmax|Y| < y_tol over the call's whole (F, N) array.  |Y| is largest
     // at the lowest frequency and the strongest field; the node maximum bounds the sampled
     // maximum from above and equals it unless |B| < ~4e-18 T ("Deviations").
-    // (np.nanmax of nothing but NaN is NaN, which is not below the tolerance: a |B| column that is NaN at every level
-    //  below the peak stays on the magnetised formulas - and gives NaN everywhere, as in the reference)
+    // (np.nanmax of nothing but NaN is NaN, which is not below the tolerance: a |B| column that leaves no sampled value
+    //  a number - NaN at every level below the peak, or at one end of every segment and at level 0 - stays on the
+    //  magnetised formulas and gives NaN everywhere, as in the reference)
     info.unmag = ((neg & 8) && (kGyro * bmax) / (fm * 1e6) < kUnmagTol) ? 1 : 0;
     info.poly_angle = trig == 5 ? 0 : (trig == 1 ? 4 : (trig == 2 ? 1 : (trig == 3 ? 2 : 3)));
     if (info.poly_angle == 4) {
