@@ -110,7 +110,14 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *   "persistent", "tail_bpp", "tail_rounds", "split_few_profiles", "split_min_points", "target_waves"
  *                        how a launch is cut into workgroups (never the value of a pair)
  *   "no_candidates", "thread_scan_min", "lean_min_points"
- *                        which of the equivalent search / loop paths a pair takes */
+ *                        which of the equivalent search / loop paths a pair takes
+ *   "local_chunks"       0: the chunks of a few-pair launch on a long grid are spread over the launch and added by a
+ *                        second kernel (1: a pair's chunks are waves of one workgroup, which adds them up itself)
+ *   "direct_upload"      0: a small host-buffer call stages its inputs in pinned memory and copies them (1: on a
+ *                        large-BAR device the CPU writes them straight into device memory)
+ *   "timing"             1: synchronous host-buffer operator calls record timing events too (0; see prhf_last_kernel_ms)
+ *   "trim_lds"           0: a column of more than 1400 levels is always staged in global memory (1: when every
+ *                        bottomside of the launch fits LDS, only the levels up to the highest peak are staged) */
 int prhf_ctx_set_option(prhf_ctx* ctx, const char* name, double value);
 
 /*
