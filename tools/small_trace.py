@@ -12,7 +12,7 @@ day = [g["Day_" + k] for k in ("den", "bmag", "bpsi", "alt")]
 f174 = synth.sounder_frequencies(1)
 dev = torch.device("cuda", 0)
 t = [torch.as_tensor(x, device=dev) for x in (f174, *day)]
-for mode, n in (("X", 20000), ("O", 200)):
+for mode, n in (("X", 20000), ("O", 200), ("O", 20000)):
     for _ in range(3):
         library.vertical_forward_operator(*t, mode, n)
     w = np.fromfile(path, dtype=np.uint64).reshape(-1, 8, 6).astype(np.float64) / 100.0
@@ -23,4 +23,5 @@ for mode, n in (("X", 20000), ("O", 200)):
                       "argmax_known_us": float((w[:, 0, 3] - w[:, 0, 0]).mean()), "nodes_staged_us": float((w[:, 0, 4] - w[:, 0, 0]).mean()),
                       "running_max_done_us": float((w[:, 0, 5] - w[:, 0, 0]).mean()),
                       "work_after_staging_us_mean": float((w[:, :, 1] - w[:, :, 2]).mean()),
+                      "work_after_staging_us_by_wave_max": [round(float(x), 1) for x in (w[:, :, 1] - w[:, :, 2]).max(axis=0)],
                       "last_end_us": float(w[:, :, 1].max() - t0)}))
