@@ -19,11 +19,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     "thread_scan_min=1e18,tail_bpp=1",
     "short_kernel=0",
     "short_queue=24",
+    "local_chunks=0,direct_upload=0,timing=1",          # round 3: chunk sums through scratch + a second kernel, staged upload
+    "trim_lds=0,shortx_kernel=0",
 ])
 def test_parity_subset_under_knobs(knobs):
     env = dict(os.environ, PRHF_TEST_OPTIONS=knobs)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-           "-k", "g1 or g5 or g10 or between_512 or below_the_gyro", "-p", "no:cacheprovider"]
+           "-k", "g1 or g4 or g5 or g10 or g13 or between_512 or below_the_gyro", "-p", "no:cacheprovider"]
     done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-2000:]
     assert " passed" in done.stdout
