@@ -33,6 +33,18 @@ if kind == "nan":
         for mode in "XO":
             want = vfo_numpy.virtual_heights_batch(freq, den, bmag, bpsi, alt, mode, n_points)
             got = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points)
+            err_, ok_ = rel_err(got, want)
+            big = ok_ & np.isfinite(got) & (err_ > (1e-7 if mode == "X" else 3e-6))
+            if big.any() and np.array_equal(np.isnan(got), np.isnan(want)):
+                noise = oracle_noise(freq, den, bmag, bpsi, alt, mode, n_points, runs=12, seed=seed) if mode == "O" else np.zeros_like(want)
+                gotf = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=library.MATH_FAITHFUL)
+                for idx in np.argwhere(big):
+                    i, j = idx
+                    if err_[i, j] > max(1e-6, 4 * noise[i, j]) or mode == "X":
+                        print("iteration", it, "mode", mode, "what", what, "victim", victim, "where", where, "n_alt", n_alt, "n_points", n_points,
+                              "pair", idx, "f", freq[j], "err", err_[i, j], "noise", noise[i, j], "want", want[i, j], "got", got[i, j], "faithful tier", gotf[i, j])
+                        print("peaks", np.argmax(np.where(np.isnan(den), np.inf, den), axis=1))
+                        print("den", den[i]); print("bmag", bmag[i]); print("bpsi", bpsi[i]); print("alt", alt if alt.ndim == 1 else alt[i])
             if not np.array_equal(np.isnan(got), np.isnan(want)):
                 print("iteration", it, "mode", mode, "what", what, "victim", victim, "where", where, "n_alt", n_alt, "n_points", n_points,
                       "n_prof", n_prof, "alt2d", alt.ndim == 2)
