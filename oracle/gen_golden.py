@@ -21,6 +21,9 @@ Fixtures:
   G8/G9  stratified Snell's-law rays, flat and spherical Earth
   G10 the first 64 profiles of BASELINE config 3 (seed 20260003) x 174 freqs, O/200 + noise floors
   G13 profiles of 2 600 / 3 096 levels (more than the kernel keeps in LDS) and NaN-padded densities
+  G14 the first 16 profiles of BASELINE config 4 (seed 20260004) x 256 freqs, X/20000 + noise floors
+  G15 the first 8 profiles of each slice of BASELINE config 5 (seed 20260005) x 512 freqs, each with its
+      slice's mode and n_points (O/200, X/2000, O/2000, X/20000) + noise floors
   G11 residual_VH (library.py:595-669) rows: the reference function itself, with model_VH replaced by
       a stand-in that builds the EDP without PyIRI and calls the reference's own operator
   G12 (made with the ORACLE, not the reference: it needs a hook inside find_mu_mup) "rounding noise" of
@@ -258,6 +261,8 @@ def main():
     gen_residual(lib)
     gen_rounding_noise(lib)
     gen_tall(lib)
+    gen_config4(lib)
+    gen_config5(lib)
     print("fixtures written to", OUT)
 
 
@@ -346,6 +351,97 @@ def gen_config3(lib):
     fin = np.isfinite(vh)
     print("G10 reflecting fraction", float(fin.mean()), "noise > 1e-6 at", int((nz[fin] > 1e-6).sum()), "of",
           int(fin.sum()), "pairs; max", float(nz[fin & np.isfinite(nz)].max()), flush=True)
+
+
+_POOL_LIB = None
+
+
+def _noise_job(job):
+    """One row of a seeded batch through the reference + its NOISE_RUNS jittered re-runs (pool worker: the
+    reference module is inherited from the parent through fork)."""
+    freq, den, bmag, bpsi, alt, mode, n_points, seed = job
+    np.seterr(all="ignore")
+    return noise_floor(_POOL_LIB, freq, den, bmag, bpsi, alt, mode, n_points, seed)
+
+
+def _noise_rows(lib, jobs, workers=8):
+    import multiprocessing as mp
+    global _POOL_LIB
+    _POOL_LIB = lib
+    with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_noise_job, jobs, chunksize=1)
+
+
+def gen_config4(lib):
+    """G14: the first 16 profiles of BASELINE config 4 (100 000 Chapman profiles, seed 20260004) x 256 freqs,
+    X mode, n_points = 20000 - the configuration the metric is quoted on - evaluated by the reference
+    (library.py:459-509), with its own +-1 ulp response per pair.  Rows 0-15 belong to rank 0's shard of the
+    8-rank cut (dist.shard_bounds) and to the 100 000-row launch alike."""
+    from pyrayhf_amd import synth
+    rows = 16
+    alt, den, bmag, bpsi = synth.chapman_profiles(100000, 20260004, rows=slice(0, rows))
+    freq = synth.sounder_frequencies(4)
+    out = _noise_rows(lib, [(freq, den[p], bmag[p], bpsi[p], alt, "X", 20000, 20260004 + 7919 * p) for p in range(rows)])
+    vh = np.array([o[0] for o in out])
+    nz = np.array([o[1] for o in out])
+    np.savez(os.path.join(OUT, "g14_config4_rows.npz"), freq=freq, alt=alt, den=den, bmag=bmag, bpsi=bpsi,
+             seed=20260004, n_points=20000, rows=np.arange(rows), X_20000_vh=vh, X_20000_noise=nz)
+    fin = np.isfinite(vh)
+    print("G14 reflecting fraction", float(fin.mean()), "noise max", float(nz[fin & np.isfinite(nz)].max()),
+          "mask flips under jitter", int(np.isinf(nz).sum()), flush=True)
+
+
+CONFIG5_SLICES = ((0, 20000, "O", 200), (20000, 35000, "X", 2000), (35000, 45000, "O", 2000), (45000, 50000, "X", 20000))
+
+
+def gen_config5(lib):
+    """G15: the first 8 profiles of each slice of BASELINE config 5 (50 000 Chapman profiles, seed 20260005,
+    512 freqs; slices as SURVEY section 8d names them), each evaluated by the reference with its slice's mode and
+    n_points, with noise floors.  The rows are global row numbers of the 50 000-row batch: they sit in rank 0's
+    cut of every slice (dist.shard_segments) and in the full work list."""
+    from pyrayhf_amd import synth
+    per = 8
+    freq = synth.sounder_frequencies(5)
+    g = {"freq": freq, "seed": 20260005, "slices": np.array([(a, b, "OX".index(m), n) for a, b, m, n in CONFIG5_SLICES])}
+    jobs, keys = [], []
+    for p0, _p1, mode, n in CONFIG5_SLICES:
+        alt, den, bmag, bpsi = synth.chapman_profiles(50000, 20260005, rows=slice(p0, p0 + per))
+        g["alt"] = alt
+        g[f"{mode}_{n}_rows"] = np.arange(p0, p0 + per)
+        g[f"{mode}_{n}_den"], g[f"{mode}_{n}_bmag"], g[f"{mode}_{n}_bpsi"] = den, bmag, bpsi
+        for p in range(per):
+            jobs.append((freq, den[p], bmag[p], bpsi[p], alt, mode, n, 20260005 + 104729 * (p0 + p) + n))
+            keys.append((mode, n, p))
+    # longest jobs first, so that the pool drains evenly
+    order = sorted(range(len(jobs)), key=lambda i: -jobs[i][6])
+    out = _noise_rows(lib, [jobs[i] for i in order])
+    res = {keys[i]: o for i, o in zip(order, out)}
+    for _p0, _p1, mode, n in CONFIG5_SLICES:
+        g[f"{mode}_{n}_vh"] = np.array([res[(mode, n, p)][0] for p in range(per)])
+        g[f"{mode}_{n}_noise"] = np.array([res[(mode, n, p)][1] for p in range(per)])
+        fin = np.isfinite(g[f"{mode}_{n}_vh"])
+        nz = g[f"{mode}_{n}_noise"]
+        print("G15", mode, n, "reflecting fraction", float(fin.mean()), "noise > 1e-6 at", int((nz[fin] > 1e-6).sum()),
+              "of", int(fin.sum()), "; max finite", float(nz[fin & np.isfinite(nz)].max()), flush=True)
+    np.savez(os.path.join(OUT, "g15_config5_rows.npz"), **g)
+    add_rounding_noise_g15(lib)
+
+
+def add_rounding_noise_g15(lib):
+    """The O-mode rows of G15 also get the rounding noise of G12 (made with the pinned ORACLE, not the reference: the
+    response to -1/0/+1 ulp in sin, cos, YT**4, YT**3), stored beside the reference's input-jitter floors."""
+    del lib
+    from oracle import vfo_numpy as orc
+    path = os.path.join(OUT, "g15_config5_rows.npz")
+    g = dict(np.load(path))
+    for n in (200, 2000):
+        g[f"O_{n}_noise_rounding"] = np.array(
+            [orc.rounding_noise(g["freq"], g[f"O_{n}_den"][p], g[f"O_{n}_bmag"][p], g[f"O_{n}_bpsi"][p], g["alt"], "O", n,
+                                runs=NOISE_RUNS, seed=int(g[f"O_{n}_rows"][p])) for p in range(g[f"O_{n}_den"].shape[0])])
+        fin = np.isfinite(g[f"O_{n}_vh"])
+        print("G15 O", n, "rounding noise > 1e-6 at", int((g[f"O_{n}_noise_rounding"][fin] > 1e-6).sum()), "of", int(fin.sum()),
+              flush=True)
+    np.savez(path, **g)
 
 
 class _Param:
@@ -534,6 +630,7 @@ if __name__ == "__main__":
         np.seterr(all="ignore")
         ref = load_reference_library()
         for what in only:
-            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual, "g12": gen_rounding_noise, "g13": gen_tall}[what](ref)
+            {"g8": gen_snell, "g10": gen_config3, "g11": gen_residual, "g12": gen_rounding_noise, "g13": gen_tall,
+             "g14": gen_config4, "g15": gen_config5, "g15r": add_rounding_noise_g15}[what](ref)
     else:
         main()

@@ -21,6 +21,17 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
+def require():
+    """The checker must not go missing silently: build the library from oracle/vfo_oracle.c if it is absent (gcc, as
+    __graft_entry__.build() does) and raise when that fails.  Tests call this instead of skipping."""
+    if not available():
+        import subprocess
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    if not available():
+        raise RuntimeError("oracle/libvfo_oracle.so is missing and could not be built (make -C oracle)")
+    return True
+
+
 def _load():
     global _lib
     if _lib is None:

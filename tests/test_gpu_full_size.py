@@ -14,7 +14,8 @@ import zlib
 import numpy as np
 import pytest
 
-from parity import assert_masks, assert_o_mode, assert_x_mode, oracle_noise, rel_err
+from conftest import load_golden
+from parity import assert_masks, assert_o_mode, assert_x_mode, combined_noise, oracle_noise, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -97,10 +98,10 @@ def test_config4_shard_x_mode_20000(lib):
     assert 0.45 < fin.mean() < 0.60
     assert np.all(vh[fin] >= alt.min()) and np.all(vh[fin] < 5000.0)
     # virtual height grows with frequency within one layer trace more often than not (sanity, not physics proof)
-    if vfo_c.available():
-        pick = np.sort(np.concatenate([[7, 4242, 9000, 12499], np.random.default_rng(4).choice(12500, 60, False)]))
-        want = vfo_c.virtual_heights_batch(freq, den[pick], bmag[pick], bpsi[pick], alt, "X", 20000)
-        assert_x_mode(vh[pick], want, tol=1e-9)
+    vfo_c.require()                            # (a missing checker is a failure, not a skipped check)
+    pick = np.sort(np.concatenate([[7, 4242, 9000, 12499], np.random.default_rng(4).choice(12500, 60, False)]))
+    want = vfo_c.virtual_heights_batch(freq, den[pick], bmag[pick], bpsi[pick], alt, "X", 20000)
+    assert_x_mode(vh[pick], want, tol=1e-9)
 
 
 def test_config5_mixed_worklist(lib):
@@ -143,6 +144,10 @@ def test_config4_all_100000_profiles_on_one_gpu(lib):
         part = lib.vertical_forward_operator(t["freq"], t["den"][lo:hi], t["bmag"][lo:hi], t["bpsi"][lo:hi], t["alt"], "X", 20000)
         assert torch.equal(torch.nan_to_num(part, nan=-1.0), torch.nan_to_num(full[lo:hi], nan=-1.0)), rank
     vh = full.cpu().numpy()
+    # rows 0-15 of this batch were evaluated by the reference itself (fixture G14)
+    g14 = load_golden("g14_config4_rows.npz")
+    assert np.array_equal(den[:16], g14["den"])
+    assert_x_mode(vh[:16], g14["X_20000_vh"])
     fin = np.isfinite(vh)
     assert 0.50 < fin.mean() < 0.53
     # (virtual heights grow without bound towards a layer's critical frequency: among 13 million reflecting pairs a
@@ -178,6 +183,14 @@ def test_config5_all_50000_profiles_on_one_gpu(lib):
         rebuilt[idx] = part
     assert torch.equal(torch.nan_to_num(rebuilt, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
     vh = full.cpu().numpy()
+    # the first eight rows of every slice were evaluated by the reference itself (fixture G15)
+    g15 = load_golden("g15_config5_rows.npz")
+    for p0, p1, mode, n in CONFIG5_SEGMENTS:
+        assert np.array_equal(den[p0:p0 + 8], g15[f"{mode}_{n}_den"])
+        if mode == "X":
+            assert_x_mode(vh[p0:p0 + 8], g15[f"X_{n}_vh"])
+        else:
+            assert_o_mode(vh[p0:p0 + 8], g15[f"O_{n}_vh"], combined_noise(g15[f"O_{n}_noise"], g15[f"O_{n}_noise_rounding"]))
     fin = np.isfinite(vh)
     assert 0.45 < fin.mean() < 0.60
     for p0, p1, mode, n in CONFIG5_SEGMENTS:

@@ -49,8 +49,7 @@ def random_problem(rng):
 def test_random_problems_against_c_oracle(seed):
     from oracle import vfo_c, vfo_numpy
     from pyrayhf_amd import library
-    if not vfo_c.available():
-        pytest.skip("oracle/libvfo_oracle.so not built")
+    vfo_c.require()
     rng = np.random.default_rng(1000 + seed)
     checked = 0
     for _ in range(40):
@@ -92,8 +91,7 @@ def test_non_uniform_grid_at_full_resolution():
     grid (and, once more, on a grid that is uniform only to 1e-10), n_points = 20000, against the C oracle."""
     from oracle import vfo_c
     from pyrayhf_amd import library, synth
-    if not vfo_c.available():
-        pytest.skip("oracle/libvfo_oracle.so not built")
+    vfo_c.require()
     rng = np.random.default_rng(77)
     freq = synth.sounder_frequencies(4)[::3]
     base = np.arange(80.0, 700.0, 1.0)
@@ -125,8 +123,7 @@ def test_tall_profiles_one_workgroup_per_cu(n_alt):
     no limit), 65 536 are refused (level indices travel as uint16)."""
     from oracle import vfo_c
     from pyrayhf_amd import library
-    if not vfo_c.available():
-        pytest.skip("oracle/libvfo_oracle.so not built")
+    vfo_c.require()
     rng = np.random.default_rng(n_alt)
     alt = np.linspace(80.0, 700.0, n_alt)
     hm = rng.uniform(250.0, 400.0, (6, 1)); h = rng.uniform(35.0, 70.0, (6, 1))
@@ -235,8 +232,7 @@ def test_random_tall_columns(seed):
     (X mode) and the NumPy oracle (O mode)."""
     from oracle import vfo_c, vfo_numpy
     from pyrayhf_amd import library
-    if not vfo_c.available():
-        pytest.skip("oracle/libvfo_oracle.so not built")
+    vfo_c.require()
     rng = np.random.default_rng(8000 + seed)
     checked = 0
     for _ in range(14):

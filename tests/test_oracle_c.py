@@ -10,7 +10,11 @@ from conftest import load_golden
 from oracle import vfo_c
 from parity import assert_masks, assert_o_mode, assert_x_mode, rel_err
 
-pytestmark = pytest.mark.skipif(not vfo_c.available(), reason="oracle/libvfo_oracle.so not built (make -C oracle)")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _checker_is_there():
+    vfo_c.require()        # built from oracle/vfo_oracle.c when absent; a missing checker fails, it does not skip
 
 
 def test_basic_and_edp_known_answers():
@@ -54,3 +58,14 @@ def test_edge_cases():
             assert_masks(vh, want)
             err, ok = rel_err(vh, want)
             assert err.max(initial=0.0) <= 2e-6, (name, mode, err.max())
+
+
+def test_config5_rows_g15():
+    """The reference-run rows at config 5's shapes (512 freqs; O/200, X/2000, O/2000, X/20000)."""
+    g = load_golden("g15_config5_rows.npz")
+    for mode, n, tol in (("X", 2000, 1e-11), ("X", 20000, 1e-11)):
+        got = vfo_c.virtual_heights_batch(g["freq"], g[f"X_{n}_den"], g[f"X_{n}_bmag"], g[f"X_{n}_bpsi"], g["alt"], "X", n)
+        assert_x_mode(got, g[f"X_{n}_vh"], tol=tol)
+    for n in (200, 2000):
+        got = vfo_c.virtual_heights_batch(g["freq"], g[f"O_{n}_den"], g[f"O_{n}_bmag"], g[f"O_{n}_bpsi"], g["alt"], "O", n)
+        assert_o_mode(got, g[f"O_{n}_vh"], np.maximum(g[f"O_{n}_noise"], g[f"O_{n}_noise_rounding"]))

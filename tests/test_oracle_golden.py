@@ -215,7 +215,7 @@ def test_tall_and_nan_padded_profiles_g13():
                 assert same_bits(orc.virtual_heights(*a, mode, 200), g[f"nanpad_{first}_{mode}_200_vh"]), (first, mode)
     # the plain-C restatement ranks a NaN density the same way
     from oracle import vfo_c
-    if vfo_c.available():
+    if vfo_c.require():
         a = [g["nanpad_freq"], g["nanpad_200_den"][None, :], g["nanpad_bmag"][None, :], g["nanpad_bpsi"][None, :],
              g["nanpad_alt"]]
         got = vfo_c.virtual_heights_batch(*a, "X", 200)[0]
@@ -239,3 +239,42 @@ def test_nan_in_alt_bmag_bpsi_g13():
                 with np.errstate(all="ignore"):
                     got = orc.virtual_heights(g["nanpad_freq"], a["den"], a["bmag"], a["bpsi"], a["alt"], mode, n)
                 assert same_bits(got, g[f"nanfield_{case}_{mode}_{n}_vh"]), (case, mode, n)
+
+
+def test_config4_rows_g14():
+    """Reference-run rows at config 4's own shape (seed 20260004, 256 freqs, X/20000): the NumPy restatement bit for
+    bit on four of the sixteen rows (4 s each), the plain-C restatement on all of them at 1e-12."""
+    from oracle import vfo_c
+    g = load_golden("g14_config4_rows.npz")
+    from pyrayhf_amd import synth
+    alt, den, bmag, bpsi = synth.chapman_profiles(100000, int(g["seed"]), rows=slice(0, 16))
+    assert same_bits(den, g["den"]) and same_bits(bmag, g["bmag"]) and same_bits(bpsi, g["bpsi"]) and same_bits(alt, g["alt"])
+    assert same_bits(synth.sounder_frequencies(4), g["freq"])
+    for p in (0, 5, 11, 15):
+        vh = orc.virtual_heights(g["freq"], g["den"][p], g["bmag"][p], g["bpsi"][p], g["alt"], "X", 20000)
+        assert same_bits(vh, g["X_20000_vh"][p]), p
+    vfo_c.require()
+    got = vfo_c.virtual_heights_batch(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "X", 20000)
+    want = g["X_20000_vh"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) <= 1e-12
+    assert np.nanmax(g["X_20000_noise"]) < 1e-10          # the reference's own +-1 ulp response at this shape
+
+
+def test_config5_rows_g15():
+    """Reference-run rows of every slice of config 5 (seed 20260005, 512 freqs): O/200, X/2000, O/2000, X/20000, the
+    first eight profiles of each slice.  NumPy restatement bit for bit (all short rows, two of each long slice)."""
+    g = load_golden("g15_config5_rows.npz")
+    from pyrayhf_amd import synth
+    assert same_bits(synth.sounder_frequencies(5), g["freq"])
+    for p0, _p1, mode_i, n in g["slices"]:
+        mode = "OX"[int(mode_i)]
+        rows = g[f"{mode}_{n}_rows"]
+        assert rows[0] == p0 and rows.size == 8
+        alt, den, bmag, bpsi = synth.chapman_profiles(50000, int(g["seed"]), rows=slice(int(rows[0]), int(rows[-1]) + 1))
+        assert same_bits(den, g[f"{mode}_{n}_den"]) and same_bits(bmag, g[f"{mode}_{n}_bmag"])
+        assert same_bits(bpsi, g[f"{mode}_{n}_bpsi"]) and same_bits(alt, g["alt"])
+        for p in (range(8) if n <= 200 else (0, 7) if n <= 2000 else (3,)):
+            vh = orc.virtual_heights(g["freq"], den[p], bmag[p], bpsi[p], alt, mode, int(n))
+            assert same_bits(vh, g[f"{mode}_{n}_vh"][p]), (mode, n, p)
