@@ -69,6 +69,9 @@ struct Knobs {
                                        // returns; prhf_last_kernel_ms keeps reporting the last launch that was timed
     double trim_lds = 1;               // columns of more than 1400 levels: stage only up to the highest peak of the launch and
                                        // stay on the LDS kernels when that fits (0: always the global-memory slabs)
+    double short_compact = 1;          // short O-mode grids: four 4-wave workgroups per CU whose staged arrays hold as many
+                                       // levels as a quarter of the LDS allows; a profile whose peak lies higher goes to a
+                                       // second launch with full-size arrays (0: two 8-wave workgroups per CU only)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -96,6 +99,7 @@ const KnobName kKnobNames[] = {
     {"direct_upload", &Knobs::direct_upload, 0, 1},
     {"timing", &Knobs::timing, 0, 1},
     {"trim_lds", &Knobs::trim_lds, 0, 1},
+    {"short_compact", &Knobs::short_compact, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -175,6 +179,7 @@ struct prhf_ctx {
     DevBuf levels;    // level table of a grouped tracer launch
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
+    DevBuf leftover_tall;   // compact short-grid launch: the profiles whose bottomside needs the full-size arrays
     DevBuf tall;         // profiles of more than kMaxAlt levels: one slab of staged levels per resident workgroup
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
@@ -399,8 +404,25 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // LDS budget of a short-grid workgroup: two per CU where its nodes allow that, else one (a few hundred bytes of
     // static LDS - tickets, counters - come on top)
     const size_t lds_half = 80 * 1024 - 512, lds_full = 160 * 1024 - 512;
-    const size_t short_budget = prhf::short_queue_entries(lds_levels, n_freq, lds_half) ? lds_half : lds_full;
-    const int short_queue = prhf::short_queue_entries(lds_levels, n_freq, short_budget);
+    const size_t short_budget = prhf::short_queue_entries(lds_levels, n_freq, lds_half, PRHF_SHORT_THREADS) ? lds_half : lds_full;
+    const int short_queue = prhf::short_queue_entries(lds_levels, n_freq, short_budget, PRHF_SHORT_THREADS);
+    // The compact geometry of the short-grid O kernel: four 4-wave workgroups per CU instead of two
+    // 8-wave ones - four independent profiles in flight per CU, so that one workgroup's staging and barrier waits are
+    // covered by three others' items (config 3: -10 %).  A quarter of the LDS holds the lists and fewer levels than
+    // the column has; a profile whose peak lies above them goes to a second launch with full-size arrays.  Taken when
+    // those arrays hold at least half of the column (PyIRI columns peak at 25 - 50 % of their height).
+    const size_t lds_quarter = (160 * 1024) / PRHF_COMPACT_WGS_PER_CU - 512;
+    long long compact_levels = 0;
+    int compact_queue = 0;
+    if (kn.short_compact != 0 && short_queue > 0) {
+        long long L = lds_levels;
+        while (L > 1 && prhf::short_lds_fixed(L, n_freq, PRHF_COMPACT_THREADS) + 8 * PRHF_COMPACT_MIN_QUEUE > lds_quarter) --L;
+        if (2 * L >= lds_levels && L >= 8 &&
+            prhf::short_lds_fixed(L, n_freq, PRHF_COMPACT_THREADS) + 8 * PRHF_COMPACT_MIN_QUEUE <= lds_quarter) {
+            compact_levels = L;
+            compact_queue = prhf::short_queue_entries(L, n_freq, lds_quarter, PRHF_COMPACT_THREADS);
+        }
+    }
     long long blocks = 0, partial_elems = 0, altmin_elems = 0, out_rows = 0;
     int launch_tier = 0;
     bool want_pairs = false;
@@ -700,7 +722,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         a.tall = static_cast<unsigned char*>(c->tall.p);
     }
     if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots))
-        HIP_TRY(hipMemsetAsync(c->d_status + 1, 0, 5 * sizeof(unsigned), c->stream));     // the launches' block queues
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, 6 * sizeof(unsigned), c->stream));         // the launches' block queues
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
     // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
@@ -742,7 +764,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if (short_blocks > 0x7fffffffLL) return fail(PRHF_EINVAL, "launch too large");
         if (short_blocks == 0) return PRHF_OK;
         as.n_blocks = short_blocks;
-        as.short_queue = kShortQueueFixed > 0 ? -std::min(kShortQueueFixed, short_queue) : short_queue;
+        as.short_queue = 0;                        // (set with the geometry below)
         as.partial = nullptr;
         as.altmin = nullptr;
         as.trace = nullptr;
@@ -762,16 +784,51 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if ((rcl = ensure(c, left, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
         as.leftover = static_cast<unsigned*>(left.p);
         HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
-        const size_t lds = xmode ? prhf::shortx_lds_bytes(lds_levels, n_freq)
-                                 : prhf::short_lds_fixed(lds_levels, n_freq) + 8 * (size_t)short_queue;
-        const long long short_slots = (long long)c->cu_count * (lds <= lds_half ? 2 : 1);
-        long long grid_short = short_blocks;
-        if (short_blocks > short_slots) {
-            as.queue = c->d_status + (xmode ? 4 : 2);
-            grid_short = short_slots;
+        if (xmode) {
+            const size_t lds = prhf::shortx_lds_bytes(lds_levels, n_freq);
+            const long long short_slots = (long long)c->cu_count * (lds <= lds_half ? 2 : 1);
+            long long grid_short = short_blocks;
+            if (short_blocks > short_slots) {
+                as.queue = c->d_status + 4;
+                grid_short = short_slots;
+            }
+            HIP_TRY(prhf::launch_vfo_shortx(as, grid_short, lds, short_stream));
+        } else {
+            const bool compact = compact_levels > 0;
+            const bool second = compact && compact_levels < lds_levels;    // some bottomsides may not fit the compact arrays
+            const int fixed_q = kShortQueueFixed > 0 ? -std::min(kShortQueueFixed, compact ? compact_queue : short_queue) : 0;
+            if (second) {
+                if ((rcl = ensure(c, c->leftover_tall, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
+                as.leftover_tall = static_cast<unsigned*>(c->leftover_tall.p);
+                HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
+            }
+            const int threads = compact ? PRHF_COMPACT_THREADS : PRHF_SHORT_THREADS;
+            const int queue_entries = compact ? compact_queue : short_queue;
+            as.lds_levels = compact ? compact_levels : lds_levels;
+            as.short_queue = fixed_q ? fixed_q : queue_entries;
+            const size_t lds = prhf::short_lds_fixed(as.lds_levels, n_freq, threads) + 8 * (size_t)queue_entries;
+            const long long short_slots = (long long)c->cu_count * (compact ? PRHF_COMPACT_WGS_PER_CU : (lds <= lds_half ? 2 : 1));
+            long long grid_short = short_blocks;
+            if (short_blocks > short_slots) {
+                as.queue = c->d_status + 2;
+                grid_short = short_slots;
+            }
+            HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, short_stream));
+            if (second) {
+                // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
+                // the device (3 us when there is none); what these leave - another input shape - joins the general list
+                prhf::KArgs a2 = as;
+                a2.trace = nullptr;
+                a2.lds_levels = lds_levels;
+                a2.short_queue = fixed_q ? -std::min(kShortQueueFixed, short_queue) : short_queue;
+                a2.block_list = as.leftover_tall;
+                a2.leftover_tall = nullptr;
+                a2.queue = c->d_status + 0;
+                const size_t lds2 = prhf::short_lds_fixed(lds_levels, n_freq, PRHF_SHORT_THREADS) + 8 * (size_t)short_queue;
+                const long long slots2 = (long long)c->cu_count * (lds2 <= lds_half ? 2 : 1);
+                HIP_TRY(prhf::launch_vfo_short(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, short_stream));
+            }
         }
-        if (xmode) HIP_TRY(prhf::launch_vfo_shortx(as, grid_short, lds, short_stream));
-        else HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, short_stream));
 #ifdef PRHF_TRACE
         if (as.trace) {                            // eight wall-clock marks per wave and block (tools/wave_trace_short.py)
             std::vector<unsigned long long> host(short_trace_words);
@@ -785,6 +842,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
 #endif
         prhf::KArgs af = as;
         af.trace = nullptr;
+        af.lds_levels = lds_levels;
+        af.leftover_tall = nullptr;
         af.block_list = as.leftover;
         af.leftover = nullptr;
         af.queue = c->d_status + (xmode ? 5 : 3);
@@ -916,6 +975,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->levels.p) (void)hipFree(c->levels.p);
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
+    if (c->leftover_tall.p) (void)hipFree(c->leftover_tall.p);
     if (c->tall.p) (void)hipFree(c->tall.p);
     for (int g = 0; g < c->n_host_grids; ++g) {
         if (c->host_grid[g].mult.p) (void)hipFree(c->host_grid[g].mult.p);

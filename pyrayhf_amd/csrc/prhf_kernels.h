@@ -36,6 +36,9 @@
 #define PRHF_SHORTX_MAX_POINTS 1024  // X mode (fast tier) up to this many points: vfo_shortx_kernel (no top-segment phase;
                                     // measured against the general kernel: -38 % at 200 points, -21 % at 500, -7 % at 1000, +6 % at 2000)
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
+#define PRHF_COMPACT_THREADS 256    // the compact geometry of the short-grid O kernel: four 4-wave workgroups per CU, staged
+#define PRHF_COMPACT_WGS_PER_CU 4   // arrays for as many levels as a quarter of the LDS holds
+#define PRHF_COMPACT_MIN_QUEUE 256  // queue entries such a workgroup has at least (a profile's unused nodes come on top)
 #define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
 #ifndef PRHF_TOP_MIN_POINTS
 #define PRHF_TOP_MIN_POINTS 1024    // grids from this many points on give their top segment a loop of its own
@@ -101,7 +104,9 @@ struct KArgs {
     int no_candidates;               // PRHF_NO_CANDIDATES=1 (A/B runs): every frequency is a work item, none is pre-filtered
     // Short-grid launches (vfo_short_kernel) and their follow-up:
     unsigned* leftover;              // [0] count, [1..] block indices of the profiles the short-grid kernel does not take
-    const unsigned* block_list;      // general kernel: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
+    unsigned* leftover_tall;         // compact short-grid launch: ... of the profiles whose bottomside its staged arrays do not
+                                     // hold (they go to the short-grid launch with full-size arrays); null: `leftover`
+    const unsigned* block_list;      // follow-up launches: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
     int short_queue;                 // entries of the short-grid kernel's LDS queue
     // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
     unsigned char* tall;
@@ -128,13 +133,13 @@ inline size_t tall_slab_bytes(long long n_alt) {
 
 // LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
 // nodes, then `queue` entries of 8 bytes (a profile with K < n_alt levels adds its unused nodes to the queue).
-inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq) {
-    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(PRHF_SHORT_THREADS / 64) * 16 * 12 +
+inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq, int threads) {
+    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(threads / 64) * 16 * 12 +
                      PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 4 + (size_t)n_freq * 2;
     return (b + 15) & ~(size_t)15;
 }
-inline size_t short_lds_fixed(long long n_alt, long long n_freq) {
-    return short_lds_lists(n_alt, n_freq) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
+inline size_t short_lds_fixed(long long n_alt, long long n_freq, int threads) {
+    return short_lds_lists(n_alt, n_freq, threads) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
 }
 // ... of the X-mode variant (vfo_shortx_kernel): no queue; f_N^2 and g_p |B| per level, three doubles and an index
 // per frequency, scratch, nodes
@@ -146,8 +151,8 @@ inline size_t shortx_lds_bytes(long long n_alt, long long n_freq) {
     return shortx_lds_lists(n_alt, n_freq) + (size_t)(n_alt + 1) * PRHF_SNODE_BYTES;
 }
 // queue entries that fit `budget` bytes beside a full node table (0: the kernel cannot run)
-inline int short_queue_entries(long long n_alt, long long n_freq, size_t budget) {
-    const size_t fixed = short_lds_fixed(n_alt, n_freq);
+inline int short_queue_entries(long long n_alt, long long n_freq, size_t budget, int threads) {
+    const size_t fixed = short_lds_fixed(n_alt, n_freq, threads);
     if (fixed + 8 * 64 > budget) return 0;
     const size_t q = (budget - fixed) / 8;
     return (int)(q > PRHF_SHORT_MAX_QUEUE ? PRHF_SHORT_MAX_QUEUE : q);
@@ -171,8 +176,8 @@ hipError_t launch_vfo_tall(const KArgs& a, long long grid_blocks, hipStream_t st
 hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_alt, long long prof_stride,
                               unsigned* max_peak, hipStream_t stream);
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
-// lds_bytes = short_lds_fixed + 8 a.short_queue
-hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
+// lds_bytes = short_lds_fixed + 8 a.short_queue; threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream);
 // the X-mode variant; lds_bytes = shortx_lds_bytes
 hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words

@@ -2365,10 +2365,16 @@ hipError_t launch_residual(const double* vh_model, const double* vh_obs, long lo
 
 #include "prhf_short.inc"
 
-hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
-    constexpr int THREADS = PRHF_SHORT_THREADS;
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream) {
     if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((vfo_short_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
+    if (threads == PRHF_COMPACT_THREADS)
+        hipLaunchKernelGGL((vfo_short_kernel<PRHF_COMPACT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_COMPACT_THREADS),
+                           lds_bytes, stream, a);
+    else if (threads == PRHF_SHORT_THREADS)
+        hipLaunchKernelGGL((vfo_short_kernel<PRHF_SHORT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_SHORT_THREADS),
+                           lds_bytes, stream, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -2397,6 +2403,7 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
                              reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS>),
+                             reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_COMPACT_THREADS>),
                              reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_SHORT_THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
