@@ -72,6 +72,9 @@ struct Knobs {
     double short_compact = 1;          // short O-mode grids: four 4-wave workgroups per CU whose staged arrays hold as many
                                        // levels as a quarter of the LDS allows; a profile whose peak lies higher goes to a
                                        // second launch with full-size arrays (0: two 8-wave workgroups per CU only)
+    double short_prio = 1;             // short-grid O kernel: wave priority of a block's items by age (1: the blocks of the last
+                                       // three resident rounds rank below everything pulled before them - config 3 -2.7 %),
+                                       // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -100,6 +103,7 @@ const KnobName kKnobNames[] = {
     {"timing", &Knobs::timing, 0, 1},
     {"trim_lds", &Knobs::trim_lds, 0, 1},
     {"short_compact", &Knobs::short_compact, 0, 1},
+    {"short_prio", &Knobs::short_prio, 0, 3},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -765,6 +769,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if (short_blocks == 0) return PRHF_OK;
         as.n_blocks = short_blocks;
         as.short_queue = 0;                        // (set with the geometry below)
+        as.short_prio = (int)kn.short_prio;
         as.partial = nullptr;
         as.altmin = nullptr;
         as.trace = nullptr;

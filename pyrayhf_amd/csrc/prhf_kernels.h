@@ -108,6 +108,7 @@ struct KArgs {
                                      // hold (they go to the short-grid launch with full-size arrays); null: `leftover`
     const unsigned* block_list;      // follow-up launches: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
     int short_queue;                 // entries of the short-grid kernel's LDS queue
+    int short_prio;                  // wave priorities of the short-grid O kernel's blocks (vfo_short_kernel)
     // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
     unsigned char* tall;
     unsigned long long tall_stride;
