@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--n-points", type=int, default=None)
     ap.add_argument("--mode", default=None, choices=["O", "X"])
     ap.add_argument("--math", default=None, choices=[None, "faithful", "fast"])
+    ap.add_argument("--gather", default="root", choices=["root", "all"],
+                    help="N > 1: result rows gathered on rank 0 alone (dist.gather: each peer's block over its own xGMI link, "
+                         "SURVEY 8e) or on every rank (all_gather_into_tensor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-profile", action="store_true")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -371,6 +374,7 @@ def main():
     out = torch.empty((p_gpu, n_freq), dtype=torch.float64, device=dev)
 
     gather_events = []                       # (before, after) the gather of every step, on torch's current stream
+    gather_dst = 0 if args.gather == "root" else None
 
     def step():
         nonlocal out
@@ -384,9 +388,9 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             if local_segs is not None:
-                pdist.gather_mixed(out, global_segs, max(p1 for _, p1, _, _ in global_segs), force=True)
+                pdist.gather_mixed(out, global_segs, max(p1 for _, p1, _, _ in global_segs), force=True, dst=gather_dst)
             else:
-                pdist.gather_rows(out, p_total, force=True)
+                pdist.gather_rows(out, p_total, force=True, dst=gather_dst)
             e1.record()
             gather_events.append((e0, e1))
 
@@ -454,7 +458,8 @@ def main():
             "config": {"workload": workload,
                        "profiles_per_gpu": p_gpu, "n_freq": n_freq, "n_points": n_points or "200/2000/20000",
                        "mode": mode, "n_alt": int(alt.size), "math": args.math or "default",
-                       "parallelism": (f"profile shards x{world}, one process per GPU, all_gather of vh rows over "
+                       "parallelism": (f"profile shards x{world}, one process per GPU, "
+                                       f"{'gather of vh rows on rank 0' if args.gather == 'root' else 'all_gather of vh rows'} over "
                                        f"{'RCCL' if backend == 'nccl' else backend}") if world > 1 else "single GPU"},
             "world_size_seen": world_seen, "backend": backend if collective else None,
             "kernel_ms_per_rank": kernel_ms_per_rank,

@@ -30,8 +30,28 @@ def shard_counts(n_items, world_size):
             for r in range(world_size)]
 
 
-def gather_rows(local, n_total, group=None, force=False):
-    """All-gather row shards (unequal row counts allowed) into ``(n_total, F)`` on every rank.
+def _exchange(send, world, group, dst):
+    """One collective over equal-sized blocks: every rank's ``send`` stacked as ``(world * rows, width)`` - on every
+    rank (``dst`` None: ``all_gather_into_tensor``) or on rank ``dst`` alone (``dist.gather``: each peer's block goes
+    to the root over its own xGMI link and nobody else holds the 205 MB of config 4; the others get None)."""
+    import torch
+    import torch.distributed as dist
+
+    if dst is None:
+        buf = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(buf, send, group=group)
+        return buf
+    if dist.get_rank(group) == dst:
+        buf = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
+        dist.gather(send, list(buf.view(world, send.shape[0], send.shape[1]).unbind(0)), dst=dst, group=group)
+        return buf
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def gather_rows(local, n_total, group=None, force=False, dst=None):
+    """Gather row shards (unequal row counts allowed) into ``(n_total, F)`` on every rank, or - ``dst`` given - on
+    that rank alone (the others return None).
 
     ``local`` is this rank's ``(P_r, F)`` tensor, where ``P_r`` follows ``shard_bounds``.
     Equal shards go through one ``all_gather_into_tensor``; ragged ones are padded to the
@@ -56,8 +76,9 @@ def gather_rows(local, n_total, group=None, force=False):
     device = local.device
     if local.is_cuda and dist.get_backend(group) == "gloo":
         local = local.cpu()          # rehearsal on one GPU box: gloo gathers host tensors only
-    buf = torch.empty((world * biggest, width), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, local, group=group)
+    buf = _exchange(local, world, group, dst)
+    if buf is None:
+        return None
     buf = buf.to(device)
     if all(c == biggest for c in counts):
         return buf
@@ -108,12 +129,13 @@ def shard_segments(segments, world_size, rank):
     return (np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)), local
 
 
-def gather_mixed(local, segments, n_total, group=None, force=False):
+def gather_mixed(local, segments, n_total, group=None, force=False, dst=None):
     """Reassemble the ``(n_total, F)`` result of a mixed work list cut by ``shard_segments``.
 
-    ``local`` holds this rank's rows in ``shard_segments`` order.  One padded all-gather, then each
+    ``local`` holds this rank's rows in ``shard_segments`` order.  One padded collective, then each
     rank's rows go back to their global positions; rows no segment covers stay NaN.  ``force``: a
-    group of one rank goes through the collective too (see ``gather_rows``).
+    group of one rank goes through the collective too (see ``gather_rows``); ``dst``: only that rank
+    assembles the result, the others return None.
     """
     import numpy as np
     import torch
@@ -124,8 +146,8 @@ def gather_mixed(local, segments, n_total, group=None, force=False):
     cuts = [shard_segments(segments, world, r)[0] for r in range(world)]
     if local.shape[0] != cuts[rank].size:
         raise ValueError("local rows do not match shard_segments for this rank")
-    full = torch.full((int(n_total), local.shape[1]), float("nan"), dtype=local.dtype, device=local.device)
     if world == 1 and not (force and dist.is_initialized()):
+        full = torch.full((int(n_total), local.shape[1]), float("nan"), dtype=local.dtype, device=local.device)
         full[torch.as_tensor(cuts[0], device=local.device)] = local
         return full
     biggest = max(max(c.size for c in cuts), 1)
@@ -134,9 +156,11 @@ def gather_mixed(local, segments, n_total, group=None, force=False):
     device = local.device
     if send.is_cuda and dist.get_backend(group) == "gloo":
         send = send.cpu()
-    buf = torch.empty((world * biggest, local.shape[1]), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    buf = _exchange(send.contiguous(), world, group, dst)
+    if buf is None:
+        return None
     buf = buf.to(device)
+    full = torch.full((int(n_total), local.shape[1]), float("nan"), dtype=local.dtype, device=device)
     for r, rows in enumerate(cuts):
         if rows.size:
             full[torch.as_tensor(rows, device=device)] = buf[r * biggest: r * biggest + rows.size]

@@ -180,3 +180,75 @@ def test_one_rank_group_forced_through_the_collective(tmp_path):
     path = str(tmp_path / "one.npy")
     mp.spawn(_one_rank_worker, args=(1, _free_port(), path), nprocs=1, join=True)
     assert bool(np.load(path)[0])
+
+
+# ---- N = 8 rehearsed on CPU: the cuts and collectives of BASELINE configs 4 and 5 at their real row counts -----------------
+def _rows_value(rows, width):
+    """A (len(rows), width) array that names its global row and column: what a rank 'computed' for those rows."""
+    return rows[:, None].astype(np.float64) * 8.0 + np.arange(width, dtype=np.float64)[None, :]
+
+
+def _n8_worker(rank, world, port, result_dir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import CONFIG5_SEGMENTS
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # (a) ragged row shards: 100 003 rows of 4 columns (100 003 = 8 x 12 500 + 3: three ranks hold one row more)
+        n = 100003
+        lo, hi = pdist.shard_bounds(n, world, rank)
+        local = torch.from_numpy(_rows_value(np.arange(lo, hi), 4))
+        everywhere = pdist.gather_rows(local, n)
+        at_root = pdist.gather_rows(local, n, dst=0)
+        assert (at_root is None) == (rank != 0)
+        # (b) config 5's segment table, cut for 8 ranks, 3 columns
+        rows, local_segs = pdist.shard_segments(CONFIG5_SEGMENTS, world, rank)
+        assert rows.size == 6250 and [b - a for a, b, _, _ in local_segs] == [2500, 1875, 1250, 625]
+        mixed_local = torch.from_numpy(_rows_value(rows, 3))
+        mixed_all = pdist.gather_mixed(mixed_local, CONFIG5_SEGMENTS, 50000)
+        mixed_root = pdist.gather_mixed(mixed_local, CONFIG5_SEGMENTS, 50000, dst=0)
+        assert (mixed_root is None) == (rank != 0)
+        # every rank holds the whole array after the all-gather variants
+        ok = bool(torch.equal(everywhere, torch.from_numpy(_rows_value(np.arange(n), 4)))
+                  and torch.equal(mixed_all, torch.from_numpy(_rows_value(np.arange(50000), 3))))
+        if rank == 0:
+            ok = ok and bool(torch.equal(at_root, everywhere) and torch.equal(mixed_root, mixed_all))
+        np.save(os.path.join(result_dir, f"ok{rank}.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_rows_and_the_config5_cut(tmp_path):
+    """World size 8 (gloo, CPU): `gather_rows` on 100 003 rows (ragged shards) and `gather_mixed` on config 5's real
+    segment table, to every rank and to rank 0 alone (`dst=0`, what bench.py uses): no 8-GPU node is available to the
+    build, so this is where an N = 8 cut of the launcher's helpers has run."""
+    mp.spawn(_n8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert all(bool(np.load(str(tmp_path / f"ok{r}.npy"))[0]) for r in range(8))
+
+
+def test_root_only_gather_two_ranks(tmp_path):
+    """`dst=0` with equal and ragged shards on two ranks, against the all-gather."""
+    mp.spawn(_root_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert bool(np.load(str(tmp_path / "root.npy"))[0])
+
+
+def _root_worker(rank, world, port, result_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for n in (6, 7):
+            lo, hi = pdist.shard_bounds(n, world, rank)
+            local = torch.from_numpy(_rows_value(np.arange(lo, hi), 5))
+            a = pdist.gather_rows(local, n)
+            r = pdist.gather_rows(local, n, dst=0)
+            ok = ok and ((r is None) if rank else bool(torch.equal(a, r)))
+        rows, _ = pdist.shard_segments(MIXED, world, rank)
+        m = torch.from_numpy(_rows_value(rows, 2))
+        a = pdist.gather_mixed(m, MIXED, 14)
+        r = pdist.gather_mixed(m, MIXED, 14, dst=0)
+        ok = ok and ((r is None) if rank else bool(torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(r, nan=-1.0))))
+        if rank == 0:
+            np.save(os.path.join(result_dir, "root.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
