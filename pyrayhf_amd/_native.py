@@ -141,20 +141,25 @@ def last_error():
     return msg.decode("utf-8", "replace") if msg else ""
 
 
+def error_for(code, msg):
+    """The exception the reference raises for the condition a PRHF_E* code stands for (``msg``: prhf_last_error of
+    the thread that made the call)."""
+    if code == ENEGDEN:
+        return ValueError("Density must be non-negative")          # reference library.py:93-94
+    if code == EPEAK0:
+        return IndexError(msg or "density peak at index 0")         # the reference fails with IndexError too
+    if code == EINVAL:
+        return ValueError(msg or "invalid argument")
+    if code == ENOMEM:
+        return MemoryError(msg)
+    return NativeLibraryError(msg or f"libprhf error {code}")
+
+
 def raise_for(code):
     """Map a PRHF_E* code to the exception the reference raises for the same condition."""
     if code == OK:
         return
-    msg = last_error()
-    if code == ENEGDEN:
-        raise ValueError("Density must be non-negative")          # reference library.py:93-94
-    if code == EPEAK0:
-        raise IndexError(msg or "density peak at index 0")         # the reference fails with IndexError too
-    if code == EINVAL:
-        raise ValueError(msg or "invalid argument")
-    if code == ENOMEM:
-        raise MemoryError(msg)
-    raise NativeLibraryError(msg or f"libprhf error {code}")
+    raise error_for(code, last_error())
 
 
 def device_count():

@@ -41,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr size_t kPackBytes = 1u << 20;
+constexpr size_t kSlabMinBytes = 16u << 20;    // host-buffer batches from this many input bytes on go in slabs (run_host_slabs)
 constexpr size_t kDirectBytes = 128u << 10;   // inputs up to this size are written by the CPU through the BAR (direct_upload)
 
 // Launch-shaping and arithmetic settings of one context (prhf_ctx_set_option).  The defaults are
@@ -75,6 +76,9 @@ struct Knobs {
     double short_prio = 1;             // short-grid O kernel: wave priority of a block's items by age (1: the blocks of the last
                                        // three resident rounds rank below everything pulled before them - config 3 -2.7 %),
                                        // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3)
+    double host_slabs = 3;             // large host-buffer batches are uploaded, evaluated and returned in this many slabs of
+                                       // profiles (10 % / 30 % / 60 %) so that the transfers of one overlap the kernel of
+                                       // another (1: one upload, one launch, one download)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
 };
@@ -104,6 +108,7 @@ const KnobName kKnobNames[] = {
     {"trim_lds", &Knobs::trim_lds, 0, 1},
     {"short_compact", &Knobs::short_compact, 0, 1},
     {"short_prio", &Knobs::short_prio, 0, 3},
+    {"host_slabs", &Knobs::host_slabs, 1, 3},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -142,6 +147,14 @@ class DeviceScope {
     DeviceScope device_scope_(dev);  \
     HIP_TRY(device_scope_.error())
 
+hipError_t create_events_untimed(hipEvent_t* ev, int n) {
+    for (int i = 0; i < n; ++i) {
+        const hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t create_events(hipEvent_t* ev, int n) {
     for (int i = 0; i < n; ++i) {
         const hipError_t e = hipEventCreate(&ev[i]);
@@ -157,6 +170,8 @@ struct prhf_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t aux_stream = nullptr;  // mixed lists: the short-grid launch runs beside the general one (fork / join by events)
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;   // host-buffer batches in slabs: uploads / downloads beside the kernels
+    hipEvent_t slab_up[3] = {}, slab_done[3] = {}, slab_free = nullptr;
     hipStream_t stream = nullptr;
     // start / stop events of the most recent launches, a ring: a caller that enqueues many launches without
     // synchronising can still read every one's device time afterwards (prhf_recent_kernel_ms)
@@ -904,6 +919,91 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     return rc;
 }
 
+// A large batch from HOST buffers (a NumPy caller with an ensemble): uploaded whole in front of one launch, the
+// transfers - pageable memory, 10 - 30 GB/s - stood in front of and behind the kernel: 56.9 ms per call for a 41.2 ms
+// kernel on config 4's shard (BENCH_r03 `host_buffers`).  Here the profiles go in three slabs of 10 %, 30 % and 60 %:
+// slab k + 1 is uploaded (stream `up_stream`) while slab k is evaluated (the context's stream, through run() on the
+// staged rows as device-resident input), and slab k's result rows travel back (`down_stream`) while slab k + 1 runs.
+// A growing slab size keeps the first kernel's wait short and every later upload behind a kernel that is about as long.
+// Values do not depend on the cut: a launch's rows do not depend on their neighbours (tests/test_gpu_full_size.py).
+int run_host_slabs(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, const double* bmag,
+                   const double* bpsi, const double* alt, int64_t n_prof, int64_t n_alt, int64_t prof_stride,
+                   int64_t alt_stride, const double* mult, int32_t n_points, int32_t mode, double* out, uint32_t flags) {
+    const bool shared_field = (flags & PRHF_FLAG_SHARED_FIELD) != 0;
+    ENTER_DEVICE(c->device);
+    const size_t n_alt_rows = alt_stride ? (size_t)n_prof : 1, n_field_rows = shared_field ? 1 : (size_t)n_prof;
+    const size_t row_bytes = (size_t)n_alt * 8;
+    const size_t elems = (size_t)n_freq + ((size_t)n_prof + 2 * n_field_rows + n_alt_rows) * (size_t)n_alt + (size_t)n_points +
+                         (size_t)n_prof * (size_t)n_freq;
+    int rc;
+    if ((rc = ensure(c, c->arena, elems * 8)) != PRHF_OK) return rc;
+    double* d_freq = static_cast<double*>(c->arena.p);
+    double* d_den = d_freq + n_freq;
+    double* d_bmag = d_den + (size_t)n_prof * n_alt;
+    double* d_bpsi = d_bmag + n_field_rows * n_alt;
+    double* d_alt = d_bpsi + n_field_rows * n_alt;
+    double* d_mult = d_alt + n_alt_rows * n_alt;
+    double* d_out = d_mult + n_points;
+    // the arena may still be read by an earlier asynchronous launch of this context: the uploads wait for it
+    HIP_TRY(hipEventRecord(c->slab_free, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->up_stream, c->slab_free, 0));
+    HIP_TRY(hipMemcpyAsync(d_freq, freq, (size_t)n_freq * 8, hipMemcpyHostToDevice, c->up_stream));
+    HIP_TRY(hipMemcpyAsync(d_mult, mult, (size_t)n_points * 8, hipMemcpyHostToDevice, c->up_stream));
+    if (!alt_stride) HIP_TRY(hipMemcpyAsync(d_alt, alt, row_bytes, hipMemcpyHostToDevice, c->up_stream));
+    if (shared_field) {
+        HIP_TRY(hipMemcpyAsync(d_bmag, bmag, row_bytes, hipMemcpyHostToDevice, c->up_stream));
+        HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, row_bytes, hipMemcpyHostToDevice, c->up_stream));
+    }
+    const int n_slabs = 3;
+    const int64_t cut[4] = {0, std::max<int64_t>(1, n_prof / 10), std::max<int64_t>(2, (n_prof * 4) / 10), n_prof};
+    const uint32_t dev_flags = PRHF_FLAG_DEVICE_PTRS | PRHF_FLAG_ASYNC | (shared_field ? PRHF_FLAG_SHARED_FIELD : 0);
+    int first_error = PRHF_OK;
+    for (int k = 0; k < n_slabs && first_error == PRHF_OK; ++k) {
+        const int64_t p0 = cut[k], rows = cut[k + 1] - cut[k];
+        if (rows <= 0) continue;
+        auto up2d = [&](double* dst, const double* src, int64_t stride) {
+            return hipMemcpy2DAsync(dst + (size_t)p0 * n_alt, row_bytes, src + (size_t)p0 * stride, (size_t)stride * 8, row_bytes,
+                                    (size_t)rows, hipMemcpyHostToDevice, c->up_stream);
+        };
+        HIP_TRY(up2d(d_den, den, prof_stride));
+        if (!shared_field) {
+            HIP_TRY(up2d(d_bmag, bmag, prof_stride));
+            HIP_TRY(up2d(d_bpsi, bpsi, prof_stride));
+        }
+        if (alt_stride) HIP_TRY(up2d(d_alt, alt, alt_stride));
+        HIP_TRY(hipEventRecord(c->slab_up[k], c->up_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->slab_up[k], 0));
+        prhf_segment seg;
+        seg.prof_begin = 0;
+        seg.prof_end = rows;
+        seg.mode = mode;
+        seg.n_points = n_points;
+        seg.mult_offset = 0;
+        seg.out_offset = 0;
+        rc = run(c, d_freq, n_freq, d_den + (size_t)p0 * n_alt, shared_field ? d_bmag : d_bmag + (size_t)p0 * n_alt,
+                 shared_field ? d_bpsi : d_bpsi + (size_t)p0 * n_alt, alt_stride ? d_alt + (size_t)p0 * n_alt : d_alt, rows, n_alt,
+                 n_alt, alt_stride ? n_alt : 0, d_mult, n_points, &seg, 1, d_out + (size_t)p0 * n_freq, dev_flags);
+        if (rc != PRHF_OK) { first_error = rc; break; }
+        HIP_TRY(hipEventRecord(c->slab_done[k], c->stream));
+        // the rows of the slab before this one go home while this one runs (issued here, behind this slab's upload:
+        // a copy from or to pageable memory holds the calling thread, and the upload is what the next kernel waits for)
+        if (k > 0) {
+            HIP_TRY(hipStreamWaitEvent(c->down_stream, c->slab_done[k - 1], 0));
+            HIP_TRY(hipMemcpyAsync(out + (size_t)cut[k - 1] * n_freq, d_out + (size_t)cut[k - 1] * n_freq,
+                                   (size_t)(cut[k] - cut[k - 1]) * n_freq * 8, hipMemcpyDeviceToHost, c->down_stream));
+        }
+    }
+    if (first_error == PRHF_OK) {
+        HIP_TRY(hipStreamWaitEvent(c->down_stream, c->slab_done[n_slabs - 1], 0));
+        HIP_TRY(hipMemcpyAsync(out + (size_t)cut[n_slabs - 1] * n_freq, d_out + (size_t)cut[n_slabs - 1] * n_freq,
+                               (size_t)(cut[n_slabs] - cut[n_slabs - 1]) * n_freq * 8, hipMemcpyDeviceToHost, c->down_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->up_stream));
+    const int rc_sync = prhf_sync(c);                  // the context's stream + the launches' status words
+    HIP_TRY(hipStreamSynchronize(c->down_stream));
+    return first_error != PRHF_OK ? first_error : rc_sync;
+}
+
 }  // namespace
 
 extern "C" {
@@ -934,6 +1034,11 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->slab_free, hipEventDisableTiming)) != hipSuccess ||
+        (e = create_events_untimed(c->slab_up, 3)) != hipSuccess ||
+        (e = create_events_untimed(c->slab_done, 3)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 8 * sizeof(unsigned))) != hipSuccess ||
@@ -996,6 +1101,13 @@ int prhf_ctx_destroy(prhf_ctx* c) {
         if (c->ring1[i]) (void)hipEventDestroy(c->ring1[i]);
     }
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
+    if (c->down_stream) { (void)hipStreamSynchronize(c->down_stream); (void)hipStreamDestroy(c->down_stream); }
+    for (int i = 0; i < 3; ++i) {
+        if (c->slab_up[i]) (void)hipEventDestroy(c->slab_up[i]);
+        if (c->slab_done[i]) (void)hipEventDestroy(c->slab_done[i]);
+    }
+    if (c->slab_free) (void)hipEventDestroy(c->slab_free);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1048,6 +1160,19 @@ int prhf_vfo_batch_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq, co
     seg.n_points = n_points;
     seg.mult_offset = 0;
     seg.out_offset = 0;
+    // a large batch from host buffers: in slabs, transfers beside the kernels (run_host_slabs).  The checks of run()
+    // that concern the whole call are made by its first slab; shapes it would refuse are left to it here too.
+    if (ctx && !(flags & PRHF_FLAG_DEVICE_PTRS) && ctx->knobs.host_slabs >= 3 && freq_mhz && den && bmag && bpsi && alt &&
+        multiplier && vh_out && n_freq >= 1 && n_alt >= 1 && n_points >= 1 && n_prof >= 64 &&
+        prof_stride_elems >= n_alt && (alt_stride_elems == 0 || alt_stride_elems >= n_alt) &&
+        (mode == PRHF_MODE_O || mode == PRHF_MODE_X) && !(flags & ~(PRHF_FLAG_GRID_STABLE | PRHF_FLAG_SHARED_FIELD)) &&
+        (size_t)n_prof * (size_t)n_alt * 24 >= kSlabMinBytes && n_alt <= kMaxAltTall && n_freq <= (1 << 20)) {
+        for (int64_t i = 1; i < n_points; ++i)
+            if (multiplier[i] < multiplier[i - 1])
+                return fail(PRHF_EINVAL, "multiplier[%lld] decreases: the stretched grid must be non-decreasing", (long long)i);
+        return run_host_slabs(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
+                              multiplier, n_points, mode, vh_out, flags);
+    }
     return run(ctx, freq_mhz, n_freq, den, bmag, bpsi, alt, n_prof, n_alt, prof_stride_elems, alt_stride_elems,
                multiplier, n_points, &seg, 1, vh_out, flags);
 }

@@ -225,7 +225,7 @@ def _ptr(x):
     return p
 
 
-def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
+def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math, devices=None):
     if type(freq) is np.ndarray and freq.ndim == 1 and freq.dtype == np.float64 and freq.flags.c_contiguous:
         f = freq
     else:
@@ -248,14 +248,103 @@ def _np_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, device, math):
     alt_stride = n_alt if a.ndim == 2 else 0
     mult = _multiplier(n_points)
     out = np.empty((n_prof, f.size), dtype=np.float64)
+    flags = (_native.FLAG_SHARED_FIELD if shared else 0) | _grid_flag(mult, n_points)
+    level = _default_math(mode_code, math)
+    if devices is not None:
+        ids = _device_list(devices)
+        if len(ids) > 1 and n_prof >= 2 * len(ids):
+            _run_on_devices(ids, f, d2, b2, p2, a, shared, alt_stride, mult, int(n_points), mode_code, level, flags, out)
+            return out
+        device = ids[0]
     ctx = _native.host_context(device)
-    ctx.set_math(_default_math(mode_code, math))
+    ctx.set_math(level)
     # (d, b, p: the caller's own array objects - their reshaped views share the address)
     rc = ctx.vfo_batch(_ptr(f), f.size, _ptr(d), _ptr(b), _ptr(p), _ptr(a),
                        n_prof, n_alt, n_alt, alt_stride, _ptr(mult), int(n_points), mode_code,
-                       out.ctypes.data, (_native.FLAG_SHARED_FIELD if shared else 0) | _grid_flag(mult, n_points))
+                       out.ctypes.data, flags)
     _native.raise_for(rc)
     return out[0] if single else out
+
+
+def _device_list(devices):
+    """``"all"`` -> every visible GPU; else a sequence of device indices (an index may repeat: two contexts on it)."""
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError("devices is 'all' or a sequence of GPU indices")
+        return list(range(_native.device_count()))
+    ids = [int(x) for x in devices]
+    if not ids:
+        raise ValueError("devices is empty")
+    return ids
+
+
+class _DeviceWorker:
+    """One host thread that owns one context on one GPU (the library's contexts are per thread and device, and ctypes
+    releases the GIL during a call): the drop-in call's way to the other GPUs of the node without a process group."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.device = device
+        self.jobs = queue.SimpleQueue()
+        self.thread = threading.Thread(target=self._loop, name=f"prhf-device-{device}", daemon=True)
+        self.thread.start()
+
+    def _loop(self):
+        while True:
+            fn, done = self.jobs.get()
+            try:
+                done.append((True, fn(_native.host_context(self.device))))
+            except BaseException as exc:                # noqa: BLE001 - handed to the caller's thread
+                done.append((False, exc))
+            finally:
+                done_event = done[0]
+                done_event.set()
+
+    def submit(self, fn):
+        import threading
+        done = [threading.Event()]
+        self.jobs.put((fn, done))
+        return done
+
+
+_device_workers = {}
+
+
+def _run_on_devices(ids, f, d2, b2, p2, a, shared, alt_stride, mult, n_points, mode_code, level, flags, out):
+    """Rows cut into contiguous blocks (``dist.shard_bounds``), one block per entry of ``ids``, each evaluated by that
+    entry's own thread and context straight into its rows of ``out`` - no process group, no collective: the result
+    rows ARE the gather.  Bit-identical to the single-device call (a launch's rows do not depend on their neighbours)."""
+    from .dist import shard_bounds
+    n_prof, n_alt = d2.shape
+    n_freq = f.size
+    pending = []
+    for slot, dev in enumerate(ids):
+        lo, hi = shard_bounds(n_prof, len(ids), slot)
+        if hi <= lo:
+            continue
+        worker = _device_workers.get((slot, dev))
+        if worker is None:
+            worker = _device_workers[(slot, dev)] = _DeviceWorker(dev)
+
+        def job(ctx, lo=lo, hi=hi):
+            ctx.set_math(level)
+            row = lo * n_alt * 8
+            return ctx.vfo_batch(f.ctypes.data, n_freq, d2.ctypes.data + row,
+                                 b2.ctypes.data + (0 if shared else row), p2.ctypes.data + (0 if shared else row),
+                                 a.ctypes.data + (row if alt_stride else 0), hi - lo, n_alt, n_alt, alt_stride,
+                                 mult.ctypes.data, n_points, mode_code, out.ctypes.data + lo * n_freq * 8, flags), _native.last_error()
+        pending.append(worker.submit(job))
+    failure = None
+    for done in pending:
+        done[0].wait()
+        ok, value = done[1]
+        if not ok:
+            failure = failure or value
+        elif value[0] != _native.OK and failure is None:
+            failure = _native.error_for(*value)        # (prhf_last_error is per thread: the worker read its own message)
+    if failure is not None:
+        raise failure
 
 
 def _torch_operator(freq, den, bmag, bpsi, alt, mode_code, n_points, math, sync, out):
@@ -323,7 +412,7 @@ def _device_grid(n_points_list, dev):
 
 
 def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200, *,
-                              device=None, math=None, sync=True, out=None):
+                              device=None, devices=None, math=None, sync=True, out=None):
     """Virtual height [km] of each sounder frequency for one profile (or a batch).
 
     Parameters are the reference's (library.py:459-484): ``freq`` MHz, ``den`` m^-3,
@@ -333,7 +422,10 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     frequency is not reflected below the density peak.
 
     Keyword-only extensions: ``device`` (GPU index for host inputs; default ``PRHF_DEVICE``
-    / ``LOCAL_RANK`` / 0), ``math`` (``MATH_FAITHFUL``: the reference's operation order at every
+    / ``LOCAL_RANK`` / 0), ``devices`` (host inputs, 2-D batches: ``"all"`` or a sequence of GPU
+    indices - the rows are cut into contiguous blocks, one per entry, each evaluated by its own
+    host thread and context straight into its rows of the result; no process group is needed, and
+    the values are those of the single-GPU call bit for bit), ``math`` (``MATH_FAITHFUL``: the reference's operation order at every
     grid point; ``MATH_FAST``: the reduced algebra at every point; default ``MATH_AUTO``: fast for
     'X'; for 'O' the reference's order where 1 - X <= 1e-5 - where it decides the answer - and the
     reduced algebra elsewhere, which reproduces the reference to 1e-10),
@@ -358,7 +450,7 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):
         return _torch_operator(freq, den, bmag, bpsi, alt, code, n_points, math, sync, out)
-    return _np_operator(freq, den, bmag, bpsi, alt, code, n_points, device, math)
+    return _np_operator(freq, den, bmag, bpsi, alt, code, n_points, device, math, devices)
 
 
 def vertical_forward_operator_mixed(freq, den, bmag, bpsi, alt, segments, *, device=None, math=None, sync=True):
