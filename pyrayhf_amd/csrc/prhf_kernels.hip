@@ -420,8 +420,7 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
                                                    const double* __restrict__ alt,
                                                    const double* __restrict__ freq, int n_freq,
                                                    int n_alt, Node* nodes, double* pf2, double* gb,
-                                                   unsigned short* hint, double* red, int capacity,
-                                                   bool warm = false) {
+                                                   unsigned short* hint, double* red, int capacity) {
 #pragma clang fp contract(off)
     constexpr int W = THREADS / 64;
     static_assert(10 * W + 3 <= PRHF_RED_DOUBLES, "reduction scratch too small");
@@ -440,13 +439,6 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
     // the grid points of the two segments next to that level (np.interp), which the sum then skips (:288) - the
     // generic loop does exactly that (phase 2 keeps such a profile out of the main loop).
     int nan_in = 0;
-    // A launch of a few workgroups (one profile x 174 frequencies: configs 1 and 2) is all latency, and phase 2's |B| and
-    // psi are a second trip to HBM behind the argmax.  `warm`: their cache lines are requested here, behind the density
-    // and altitude loads, and are in L2 when phase 2 asks for them (a persistent launch does not: it would read the
-    // topside of every column, which nothing needs).
-    double touch = 0.0;
-    if (warm)
-        for (int i = tid; i < n_alt; i += THREADS) touch += bmag[i] + bpsi[i];
     for (int i = tid; i < n_alt; i += THREADS) {
         const double v = den[i], al = alt[i];
         const double key = (v != v) ? __builtin_inf() : v;
@@ -454,7 +446,6 @@ __device__ __forceinline__ BlockInfo stage_profile(const double* __restrict__ de
         amin = fmin(amin, al);
         nan_in |= (al != al) ? 1 : 0;
     }
-    asm volatile("" :: "v"(touch));
     double fm = __builtin_inf();
     for (int i = tid; i < n_freq; i += THREADS) fm = fmin(fm, fabs(freq[i]));
     {
@@ -1749,7 +1740,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 }  // namespace
 
 // Returns the wall clock at the end of staging in -DPRHF_TRACE builds (0 otherwise).
-template <int TIER, int THREADS, bool MAY_WARM>
+template <int TIER, int THREADS>
 __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
                                           unsigned short* hint, unsigned short* cand, int* cand_count, double* red,
                                           long long prof_local, int block_in_prof, int blocks_per_prof,
@@ -1757,8 +1748,7 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
     const long long p = sg.prof_begin + prof_local;
     BlockInfo info = stage_profile<TIER, THREADS>(
         a.den + p * a.prof_stride, a.bmag + p * a.field_stride, a.bpsi + p * a.field_stride,
-        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red, (int)a.lds_levels,
-        MAY_WARM && a.queue == nullptr && a.block_list == nullptr);
+        a.alt + p * a.alt_stride, a.freq, (int)a.n_freq, (int)a.n_alt, nodes, pf2, gb, hint, red, (int)a.lds_levels);
     PRHF_MARK(1);
     if (sg.mode == PRHF_KMODE_X && info.nan_b && !info.bad) info.bad = kNanRow;     // (see stage_profile)
     if (sg.mode == PRHF_KMODE_O && !info.bad) prefix_max_in_place<THREADS>(pf2, info.K, red);
@@ -1884,9 +1874,9 @@ __device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
         }
 
         const unsigned long long t_staged = (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-            ? run_block<0, THREADS, !TALL>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+            ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
                                     &item_next)
-            : run_block<1, THREADS, !TALL>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+            : run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
                                     &item_next);
         (void)t_staged;
 #ifdef PRHF_TRACE
