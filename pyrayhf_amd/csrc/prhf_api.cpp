@@ -1477,12 +1477,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         a.levels = static_cast<double*>(c->levels.p);
     } else {
         a.freq_hz = d_keyf; a.prof_idx = d_keyp;
-        // per-ray launch: one slab of mu / mu' per resident wavefront (the level table's buffer is free here)
-        long long waves = 0;
-        HIP_TRY(prhf::snell_resident_waves(n_alt, c->cu_count, &waves));
-        int rc3 = ensure(c, c->levels, (size_t)waves * 2 * (size_t)(n_alt + 1) * 8);
-        if (rc3 != PRHF_OK) return rc3;
-        a.ray_scratch = static_cast<double*>(c->levels.p);
+        // per-ray launch: persistent wavefronts drawing rays from a queue
         a.ray_queue = c->d_status + 6;
     }
     a.resident_cus = c->cu_count;

@@ -228,10 +228,7 @@ struct SnellArgs {
     const long long* group_prof; // (n_groups) or null: profile 0
     long long n_groups;
     double* levels;              // (n_groups, n_alt + 1, 2) mu and mu' of every level (ground level first when inserted)
-    // Per-ray launch: mu and mu' of a ray's compacted levels live in a slab of global memory that belongs to the
-    // resident wavefront (ray_scratch + blockIdx.x * 2 (n_alt + 1) doubles), not in LDS; the launch is persistent
-    // (ray_queue: next ray index - gridDim.x, zero at launch).  Filled in by launch_snell from `scratch_*`.
-    double* ray_scratch;
+    // Per-ray launch: persistent (ray_queue: next batch of rays - gridDim.x, zero at launch)
     unsigned* ray_queue;
     int resident_cus;            // multiprocessors of the device (sizes the persistent grid)
     double* prof_info;           // (n_prof, 2) scratch: max|B| and "has a negative density", filled by launch_snell
@@ -249,8 +246,7 @@ struct SnellArgs {
     int max_substeps;
 };
 hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
-// wavefronts of the per-ray kernel that one device keeps resident (a.ray_scratch must hold that many slabs of
-// 2 (n_alt + 1) doubles); cu_count: multiprocessors of the device
+// wavefronts of the per-ray kernel that one device keeps resident; cu_count: multiprocessors of the device
 hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves);
 
 // residual / cost may be null

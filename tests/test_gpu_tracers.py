@@ -132,8 +132,12 @@ def test_spherical_single_ray_and_flat_limit():
 @pytest.mark.parametrize("spherical", [False, True])
 def test_fan_shares_the_levels_and_changes_nothing(spherical):
     """prhf_snell_fan_f64: the refractive-index levels once per (profile, frequency), read by every elevation of the
-    fan.  Same arithmetic, so bit for bit the per-ray call's outputs - scalars and paths - and, through them, the
-    reference's rays (fixtures G8 / G9 are fans: 8 or 5 frequencies x 7 or 6 elevations per mode)."""
+    fan.  Same levels, same bracket, same up-leg increments as the per-ray call - whose kernel (round 4) makes ONE pass
+    over the levels and takes the mirrored half of the path by symmetry, where the fan kernel, with the table in reach,
+    walks the mirrored path as the reference does: the two agree to 1e-13 in every scalar and path node (measured
+    1e-15), the same rays turn, the paths have the same nodes; the midpoint - the first node at half the path, which
+    the reference's own rounding puts on the apex or on its neighbour - is the apex itself in the per-ray call.
+    Through the per-ray call's test both are held to the reference's rays (fixtures G8 / G9 are fans)."""
     from pyrayhf_amd import tracers
     g = load_golden("g8_snell.npz")
     for name in ("gauss", "day"):
@@ -146,10 +150,21 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
             fan = fan_fn(freqs, elevs, *prof, mode, return_paths=True)
             ff, ee = np.meshgrid(freqs, elevs, indexing="ij")
             rays = ray_fn(ff.ravel(), ee.ravel(), *prof, mode, return_paths=True)
-            for key in ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km", "x_turn_km",
-                        "z_turn_km", "n_path", "x", "z"):
+            for key in ("group_path_km", "group_delay_sec", "ground_range_km", "x_turn_km", "z_turn_km", "n_path", "x", "z"):
                 assert fan[key].shape[:2] == (freqs.size, elevs.size)
-                assert np.array_equal(fan[key].reshape(rays[key].shape), rays[key], equal_nan=True), (name, mode, key)
+                got, want = fan[key].reshape(rays[key].shape), rays[key]
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (name, mode, key)
+                if key == "n_path":
+                    assert np.array_equal(got, want), (name, mode, key)
+                else:
+                    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12, equal_nan=True, err_msg=f"{name} {mode} {key}")
+            # midpoints: the per-ray call's is the apex; the fan's the apex or a neighbour (the reference's search)
+            n_path = rays["n_path"]
+            fx = fan["x_midpoint"].reshape(n_path.shape)
+            for k in np.nonzero(n_path > 0)[0]:
+                apex = int(n_path[k]) // 2
+                assert abs(rays["x_midpoint"][k] - rays["x"][k, apex]) <= 1e-12 * max(1.0, abs(rays["x"][k, apex]))
+                assert any(abs(fx[k] - rays["x"][k, j]) <= 1e-9 * max(1.0, abs(rays["x"][k, j])) for j in (apex - 1, apex, apex + 1))
             assert np.isfinite(fan["group_path_km"]).any() and np.isnan(fan["group_path_km"]).any()
     # several profiles: (P, F, E)
     two = [np.stack([g["gauss_den"], 0.5 * g["gauss_den"]]), np.stack([g["gauss_bmag"]] * 2), np.stack([g["gauss_bpsi"]] * 2)]
