@@ -11,6 +11,12 @@ python bench.py --workload config3 --steps 20 --no-single-profile > $OUT/bench_$
 python bench.py --workload config5 --steps 10 --no-single-profile > $OUT/bench_${TAG}_config5.json 2> $OUT/bench_c5.err; echo "config5 rc=$?"
 python bench.py --gpus 1 --force-collective --steps 5 --no-cpu-baseline --no-single-profile --no-legs > $OUT/bench_${TAG}_n1_rccl.json 2> $OUT/bench_rccl.err; echo "rccl rc=$?"
 PRHF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --no-cpu-baseline > $OUT/bench_${TAG}_n2_rehearsal.json 2> $OUT/bench_n2.err; echo "n2 rc=$?"
+# more ranks on the one GPU (the box admits six processes on the card and the launcher holds it open too - a six-rank
+# run was killed by the process guard: four ranks here, N = 8 itself is rehearsed on CPU, tests/test_dist_gloo.py)
+PRHF_BENCH_BACKEND=gloo python bench.py --gpus 4 --profiles 256 --steps 3 --no-cpu-baseline --no-single-profile --no-legs > $OUT/bench_${TAG}_n4_rehearsal.json 2> $OUT/bench_n4.err; echo "n4 rc=$?"
+PRHF_BENCH_BACKEND=gloo python bench.py --gpus 4 --workload config5 --profiles 256 --steps 3 --no-cpu-baseline --no-single-profile --no-legs > $OUT/bench_${TAG}_config5_n4_rehearsal.json 2> $OUT/bench_c5n4.err; echo "c5 n4 rc=$?"
+python tools/tracer_workload.py > $OUT/bench_tracers_$TAG.jsonl 2>/dev/null
+python tools/tracer_fan_workload.py > $OUT/bench_tracer_fan_$TAG.jsonl 2>/dev/null
 python tools/stage_cost3.py > $OUT/stage_cost3_$TAG.jsonl 2>/dev/null
 python tools/bench_generic_path.py > $OUT/bench_generic_path_$TAG.jsonl 2>/dev/null
 python tools/time_dropin.py > $OUT/time_dropin_$TAG.jsonl 2>/dev/null
@@ -24,5 +30,6 @@ tools/profile.sh ${TAG}_config4 > /dev/null 2>&1; echo "prof config4 done"
 tools/profile.sh ${TAG}_config3 --workload config3 > /dev/null 2>&1; echo "prof config3 done"
 tools/profile.sh ${TAG}_config5 --workload config5 > /dev/null 2>&1; echo "prof config5 done"
 tools/profile.sh ${TAG}_config2 --profiles 1 --freqs 174 > /dev/null 2>&1; echo "prof config2 done"
+PROF_CMD="python3 tools/tracer_workload.py" tools/profile.sh ${TAG}_snell > /dev/null 2>&1; echo "prof snell done"
 fi
 echo "final measurements done"
