@@ -269,3 +269,51 @@ def test_random_tall_columns(seed):
                 raise AssertionError(f"seed {seed} trim {trim} levels {n_tall} n_points {n_points}: {exc}") from None
             checked += 2
     assert checked > 20
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_compact_short_grid_geometry_changes_nothing(seed):
+    """Short O-mode grids run on four 4-wave workgroups per CU whose staged arrays hold part of the column (round 4);
+    profiles that peak above them take a second launch with full-size arrays, other input shapes the general kernel.
+    Random batches - columns of 150 - 1300 levels, layers peaking anywhere in them, valleys, plateaus, a vacuum at the
+    bottom, fast-turning field angles, non-uniform altitudes in some - must come out bit for bit as with
+    `short_compact = 0` (two 8-wave workgroups, one launch), with a full and with a tiny queue."""
+    from pyrayhf_amd import library
+    rng = np.random.default_rng(40400 + seed)
+    try:
+        for _ in range(5):
+            n_alt = int(rng.choice([150, 400, 620, 900, 1300]))
+            alt = 80.0 + np.arange(n_alt) * rng.uniform(0.4, 1.5)
+            if rng.random() < 0.25:
+                alt = 70.0 + np.cumsum(rng.uniform(0.3, 1.2, n_alt))
+            P = int(rng.integers(40, 90))
+            hm = rng.uniform(alt[n_alt // 8], alt[-1] * 1.02, (P, 1))
+            h1 = rng.uniform(20, 70, (P, 1))
+            den = 10.0 ** rng.uniform(10.8, 12.6, (P, 1)) * np.exp(0.5 * (1 - (alt - hm) / h1 - np.exp(-(alt - hm) / h1)))
+            if rng.random() < 0.5:
+                den = den + 10.0 ** rng.uniform(10.0, 11.4, (P, 1)) * np.exp(-((alt - alt[n_alt // 6]) / rng.uniform(3, 15)) ** 2)
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, n_alt - 1))
+                den[:, k + 1] = den[:, k]
+            if rng.random() < 0.2:
+                den[:, 0] = 0.0
+            bmag = rng.uniform(2e-5, 6e-5, (P, 1)) * (1.0 - 3e-4 * (alt - alt[0])) + np.zeros((P, n_alt))
+            bpsi = rng.uniform(1.0, 89.0, (P, 1)) + rng.choice([0.0, 0.001, 0.06]) * (alt - alt[0]) + np.zeros((P, n_alt))
+            F = int(rng.integers(60, 260))
+            freq = np.sort(rng.uniform(0.4, 15.0, F))
+            if P * F < 4096 or np.any(np.argmax(den, axis=1) == 0):
+                continue
+            n = int(rng.choice([64, 200, 333, 1024]))
+            outs = {}
+            for compact in (0, 1):
+                library.set_option("short_compact", compact)
+                for q in (0, 24):
+                    library.set_option("short_queue", q)
+                    outs[(compact, q)] = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", n)
+            base = outs[(0, 0)]
+            assert np.isfinite(base).any()
+            for key, got in outs.items():
+                assert np.array_equal(got, base, equal_nan=True), (seed, n_alt, F, n, key)
+    finally:
+        library.set_option("short_compact", 1)
+        library.set_option("short_queue", 0)
