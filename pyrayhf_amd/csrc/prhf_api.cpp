@@ -76,6 +76,8 @@ struct Knobs {
     double short_prio = 1;             // short-grid O kernel: wave priority of a block's items by age (1: the blocks of the last
                                        // three resident rounds rank below everything pulled before them - config 3 -2.7 %),
                                        // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3)
+    double short_order = 1;            // long short-grid O launches draw their blocks in descending order of a cost estimate
+                                       // (a pre-pass over sixteen samples of every density column; 0: index order)
     double host_slabs = 3;             // large host-buffer batches are uploaded, evaluated and returned in this many slabs of
                                        // profiles (10 % / 30 % / 60 %) so that the transfers of one overlap the kernel of
                                        // another (1: one upload, one launch, one download)
@@ -109,6 +111,7 @@ const KnobName kKnobNames[] = {
     {"short_compact", &Knobs::short_compact, 0, 1},
     {"short_prio", &Knobs::short_prio, 0, 3},
     {"host_slabs", &Knobs::host_slabs, 1, 3},
+    {"short_order", &Knobs::short_order, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -199,6 +202,7 @@ struct prhf_ctx {
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
     DevBuf leftover_tall;   // compact short-grid launch: the profiles whose bottomside needs the full-size arrays
+    DevBuf order;           // short-grid launch: its blocks by cost class (short_order_kernel)
     DevBuf tall;         // profiles of more than kMaxAlt levels: one slab of staged levels per resident workgroup
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
     int64_t pairs_len = 0;
@@ -472,7 +476,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         s.mode = u.mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
         s.n_points = u.n_points;
         s.tier = c->math == PRHF_MATH_AUTO ? (u.mode == PRHF_MODE_O ? 0 : 1) : (c->math == PRHF_MATH_FAST ? 1 : 0);
-        // AUTO, O mode: the reference's operation order where it decides the answer (1 - X <= 1e-4), the
+        // AUTO, O mode: the reference's operation order where it decides the answer (1 - X <= well_conditioned = 1e-5), the
         // reduced algebra elsewhere; PRHF_MATH_FAITHFUL keeps the reference's order everywhere
         s.well_conditioned = (c->math == PRHF_MATH_AUTO && s.tier == 0) ? kWellConditioned : HUGE_VAL;
         launch_tier = (i == 0 || launch_tier == s.tier) ? s.tier : 2;
@@ -833,6 +837,16 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 as.queue = c->d_status + 2;
                 grid_short = short_slots;
             }
+            // from four resident rounds on, the blocks are drawn in descending order of a cost estimate
+            as.order = nullptr;
+            if (kn.short_order != 0 && short_blocks >= 4 * short_slots && as.ftab) {
+                const size_t words = PRHF_ORDER_CLASSES * (size_t)(short_blocks + 1);
+                if ((rcl = ensure(c, c->order, words * sizeof(unsigned))) != PRHF_OK) return rcl;
+                unsigned* order = static_cast<unsigned*>(c->order.p);
+                HIP_TRY(hipMemsetAsync(order, 0, PRHF_ORDER_CLASSES * sizeof(unsigned), short_stream));
+                HIP_TRY(prhf::launch_short_order(as, order, short_stream));
+                as.order = order;
+            }
             HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, short_stream));
             if (second) {
                 // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
@@ -842,6 +856,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 a2.lds_levels = lds_levels;
                 a2.short_queue = fixed_q ? -std::min(kShortQueueFixed, short_queue) : short_queue;
                 a2.block_list = as.leftover_tall;
+                a2.order = nullptr;
                 a2.leftover_tall = nullptr;
                 a2.queue = c->d_status + 0;
                 const size_t lds2 = prhf::short_lds_fixed(lds_levels, n_freq, PRHF_SHORT_THREADS) + 8 * (size_t)short_queue;
@@ -864,6 +879,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         af.trace = nullptr;
         af.lds_levels = lds_levels;
         af.leftover_tall = nullptr;
+        af.order = nullptr;
         af.block_list = as.leftover;
         af.leftover = nullptr;
         af.queue = c->d_status + (xmode ? 5 : 3);
@@ -1086,6 +1102,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
     if (c->leftover_tall.p) (void)hipFree(c->leftover_tall.p);
+    if (c->order.p) (void)hipFree(c->order.p);
     if (c->tall.p) (void)hipFree(c->tall.p);
     for (int g = 0; g < c->n_host_grids; ++g) {
         if (c->host_grid[g].mult.p) (void)hipFree(c->host_grid[g].mult.p);

@@ -36,6 +36,7 @@
 #define PRHF_SHORTX_MAX_POINTS 1024  // X mode (fast tier) up to this many points: vfo_shortx_kernel (no top-segment phase;
                                     // measured against the general kernel: -38 % at 200 points, -21 % at 500, -7 % at 1000, +6 % at 2000)
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
+#define PRHF_ORDER_CLASSES 16       // cost classes of the short-grid launch's block order (short_order_kernel)
 #define PRHF_COMPACT_THREADS 256    // the compact geometry of the short-grid O kernel: four 4-wave workgroups per CU, staged
 #define PRHF_COMPACT_WGS_PER_CU 4   // arrays for as many levels as a quarter of the LDS holds
 #define PRHF_COMPACT_MIN_QUEUE 256  // queue entries such a workgroup has at least (a profile's unused nodes come on top)
@@ -109,6 +110,7 @@ struct KArgs {
     const unsigned* block_list;      // follow-up launches: evaluate blocks block_list[1 .. block_list[0]] instead of 0 .. n_blocks
     int short_queue;                 // entries of the short-grid kernel's LDS queue
     int short_prio;                  // wave priorities of the short-grid O kernel's blocks (vfo_short_kernel)
+    const unsigned* order;           // short-grid O launch: its blocks by cost class (short_order_kernel), or null: index order
     // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
     unsigned char* tall;
     unsigned long long tall_stride;
@@ -179,6 +181,9 @@ hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_a
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue; threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream);
+// the blocks of the short-grid launch `a` sorted into cost classes: order[0 .. CLASSES) counts (zeroed by the caller),
+// then CLASSES lists of a.n_blocks entries
+hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream);
 // the X-mode variant; lds_bytes = shortx_lds_bytes
 hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words

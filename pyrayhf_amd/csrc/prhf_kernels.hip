@@ -1952,18 +1952,26 @@ __global__ void freq_table_kernel(const double* __restrict__ freq_mhz, long long
 }
 
 // Row n_freq of the table: min |freq_mhz| over the launch (the isotropic test of library.py:201 needs the lowest
-// frequency; the short-grid kernel reads it here instead of scanning the frequencies once per profile).
+// frequency; the short-grid kernel reads it here instead of scanning the frequencies once per profile) and, in
+// its second word, the largest finite |freq_mhz| (short_order_kernel's scale).
 __global__ void freq_min_kernel(const double* __restrict__ freq_mhz, long long n_freq, double* __restrict__ tab) {
     __shared__ double part[4];
-    double fm = __builtin_inf();
-    for (long long i = threadIdx.x; i < n_freq; i += blockDim.x) fm = fmin(fm, fabs(freq_mhz[i]));
+    __shared__ double part_max[4];
+    double fm = __builtin_inf(), fx = 0.0;
+    for (long long i = threadIdx.x; i < n_freq; i += blockDim.x) {
+        const double v = fabs(freq_mhz[i]);
+        fm = fmin(fm, v);
+        if (v < __builtin_inf()) fx = fmax(fx, v);             // (the largest finite one: the block-ordering proxy's scale)
+    }
     fm = wave_min(fm);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = fm;
+    fx = wave_max(fx);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = fm; part_max[threadIdx.x >> 6] = fx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double* row = tab + 8 * n_freq;
         row[0] = fmin(fmin(part[0], part[1]), fmin(part[2], part[3]));
-        for (int k = 1; k < 8; ++k) row[k] = 0.0;
+        row[1] = fmax(fmax(part_max[0], part_max[1]), fmax(part_max[2], part_max[3]));
+        for (int k = 2; k < 8; ++k) row[k] = 0.0;
     }
 }
 
@@ -2375,6 +2383,12 @@ hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_by
                            lds_bytes, stream, a);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream) {
+    if (a.n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(short_order_kernel, dim3((unsigned)((a.n_blocks + 63) / 64)), dim3(1024), 0, stream, a, order);
     return hipGetLastError();
 }
 
