@@ -38,8 +38,12 @@
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
 #define PRHF_ORDER_CLASSES 16       // cost classes of the short-grid launch's block order (short_order_kernel)
 #define PRHF_COMPACT_THREADS 256    // the compact geometry of the short-grid O kernel: four 4-wave workgroups per CU, staged
+#ifndef PRHF_COMPACT_WGS_PER_CU
 #define PRHF_COMPACT_WGS_PER_CU 4   // arrays for as many levels as a quarter of the LDS holds
+#endif
+#ifndef PRHF_COMPACT_MIN_QUEUE
 #define PRHF_COMPACT_MIN_QUEUE 256  // queue entries such a workgroup has at least (a profile's unused nodes come on top)
+#endif
 #define PRHF_PAIR_PAD 256           // entries behind the pair table that the main loop's prefetch may touch
 #ifndef PRHF_TOP_MIN_POINTS
 #define PRHF_TOP_MIN_POINTS 1024    // grids from this many points on give their top segment a loop of its own

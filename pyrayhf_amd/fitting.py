@@ -22,7 +22,8 @@ import numpy as np
 from . import _native
 from .library import _mode_code, _multiplier, _as_rows, _is_torch, _device_grid, _grid_flag, MATH_AUTO
 
-__all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace", "brute_grid", "minimize_parameters"]
+__all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace", "brute_grid", "minimize_parameters",
+           "resolve_method", "BoundedPair"]
 
 
 def _sorted_finite(freq, vh_obs):
@@ -187,6 +188,119 @@ def brute_grid(value, percent_sigma=20.0, step=1.0):
     return np.arange(value - sigma, value + sigma, float(step))
 
 
+# ---- the reference's other `method` values (library.py:696-704, :794-798: lmfit.minimize(..., method=method)) ---------
+# lmfit is not installed here and not vendored by the reference (pyproject.toml:41), so what it does with a method name
+# is restated from its documentation ("parity unpinned" for the optimiser's path; every residual it evaluates is the
+# pinned one, fixture G11):
+#   * names are matched as Minimizer.minimize matches them - 'leasts*' -> MINPACK Levenberg-Marquardt (leastsq),
+#     'least_s*' -> scipy least_squares (trust region reflective, bounds handed over as they are), 'brute',
+#     'differential_evolution'; any other name is looked up among the scalar minimisers by prefix of lmfit's key or of
+#     SciPy's name, and a name that matches nothing runs Nelder-Mead (scalar_minimize's default) - which is what the
+#     reference's docstring example "levenberg-marquardt" ends up as;
+#   * a parameter with both bounds is optimised through the MINUIT transform lmfit documents ("Bounds implementation"):
+#     internal = arcsin(2 (v - min) / (max - min) - 1), v = min + (sin(internal) + 1) (max - min) / 2;
+#   * a scalar minimiser sees the sum of squares of the residual array; leastsq runs with lmfit's defaults
+#     (ftol = xtol = gtol = 1e-7, maxfev = 2000 (n + 1)); scalar minimisers with maxiter = 1000 (n + 1).
+# MI355X side: every optimiser step that needs several residuals at once is ONE launch - the forward-difference
+# Jacobian of Levenberg-Marquardt (MINPACK's fdjac2 steps: h = sqrt(eps) |x|), a whole generation of differential
+# evolution - through residual_VH_batch; single evaluations go through the same entry point with one candidate.
+_SCALAR_METHODS = {
+    'nelder': 'Nelder-Mead', 'powell': 'Powell', 'cg': 'CG', 'bfgs': 'BFGS', 'lbfgsb': 'L-BFGS-B', 'tnc': 'TNC',
+    'cobyla': 'COBYLA', 'slsqp': 'SLSQP', 'trust-constr': 'trust-constr',
+}
+# (lmfit's table also lists newton, dogleg, trust-ncg, trust-exact, trust-krylov: they need a user Jacobian / Hessian,
+#  which the reference never passes - lmfit raises for them, and so does resolve_method)
+_NEEDS_DERIVATIVES = {'newton': 'Newton-CG', 'dogleg': 'dogleg', 'trust-ncg': 'trust-ncg', 'trust-exact': 'trust-exact',
+                      'trust-krylov': 'trust-krylov'}
+_NOT_RESTATED = ('basinhopping', 'ampgo', 'shgo', 'dual_annealing', 'emcee')
+
+
+def resolve_method(method):
+    """What ``lmfit.minimize(..., method=method)`` runs for a method name, as ``(family, scipy_name)`` with family one of
+    ``'brute'``, ``'leastsq'``, ``'least_squares'``, ``'differential_evolution'``, ``'scalar'``."""
+    m = str(method).lower()
+    if m.startswith('leasts'):
+        return 'leastsq', None
+    if m.startswith('least_s'):
+        return 'least_squares', None
+    if m == 'brute':
+        return 'brute', None
+    if m in _NOT_RESTATED:
+        raise NotImplementedError(f"method={method!r}: lmfit's {m} driver is not restated here")
+    if m and 'differential_evolution'.startswith(m):
+        return 'differential_evolution', None
+    chosen = 'Nelder-Mead'                                 # scalar_minimize's default when nothing matches
+    for key, val in {**_SCALAR_METHODS, **_NEEDS_DERIVATIVES}.items():
+        if m and (key.startswith(m) or val.lower().startswith(m)):
+            chosen = val
+    if chosen in _NEEDS_DERIVATIVES.values():
+        raise NotImplementedError(f"method={method!r} needs a Jacobian the reference never supplies (lmfit raises too)")
+    return 'scalar', chosen
+
+
+class BoundedPair:
+    """The two fitted parameters with lmfit's bounds transform: ``min = value - sigma``, ``max = value + sigma``
+    (library.py:746-757, :783-792)."""
+
+    def __init__(self, values, sigmas):
+        self.value = np.asarray(values, dtype=np.float64)
+        sig = np.abs(np.asarray(sigmas, dtype=np.float64))
+        self.lo, self.hi = self.value - sig, self.value + sig
+        if not np.all(self.hi > self.lo):
+            raise ValueError("percent_sigma leaves no room around an initial value")
+
+    def to_internal(self, v):
+        return np.arcsin(2.0 * (np.asarray(v, dtype=np.float64) - self.lo) / (self.hi - self.lo) - 1.0)
+
+    def from_internal(self, x):
+        return self.lo + (np.sin(np.asarray(x, dtype=np.float64)) + 1.0) * (self.hi - self.lo) / 2.0
+
+
+def _local_search(residuals, pair, family, scipy_name):
+    """Run one of lmfit's local / population optimisers on ``residuals(nodes (P, 2)) -> (P, F)``; returns the fitted
+    pair of external values."""
+    from scipy import optimize
+
+    def one(v):
+        return residuals(np.asarray(v, dtype=np.float64).reshape(1, 2))[0]
+
+    if family == 'least_squares':                          # bounds as they are, no transform (lmfit.least_squares)
+        sol = optimize.least_squares(one, pair.value, bounds=(pair.lo, pair.hi))
+        return sol.x
+    if family == 'differential_evolution':                 # bounds as they are; a generation = one launch
+        def cost_columns(x):                               # SciPy hands over (2, S)
+            r = residuals(np.ascontiguousarray(x.T))
+            return np.nan_to_num((r * r).sum(axis=1), nan=np.inf)
+        sol = optimize.differential_evolution(cost_columns, list(zip(pair.lo, pair.hi)), vectorized=True,
+                                              updating='deferred', seed=0, polish=False)
+        return sol.x
+    x0 = pair.to_internal(pair.value)
+    # the start sits in the middle of its bounds, i.e. at internal 0 - up to the rounding of value -+ sigma.  MINPACK
+    # sizes its first trust region by |x0| (100 |D x0|, or 100 when that is 0): a start of 1e-16 instead of 0 gives a
+    # region of 1e-11 and the search ends where it began.  Exactly 0 is what the transform means there.
+    x0 = np.where(np.abs(x0) < 1e-9, 0.0, x0)
+    if family == 'leastsq':
+        eps = np.sqrt(np.finfo(np.float64).eps)            # fdjac2 with epsfcn = 0: h = eps |x| (eps where x == 0)
+
+        def jac(x):
+            # ... with a floor: the internal variables are angles in [-pi/2, pi/2], and a start in the middle of its
+            # bounds is 0 only up to rounding (value - sigma, value + sigma are rounded): MINPACK's rule then steps by
+            # 1e-8 x 1e-16, the column comes out as zeros and Levenberg-Marquardt stops where it started
+            h = eps * np.maximum(np.abs(x), 1.0)
+            pts = np.vstack([x, x + np.diag(h)])           # f(x) and the n forward steps: one launch
+            r = residuals(pair.from_internal(pts))
+            return ((r[1:] - r[0]) / h[:, None]).T
+        x, _, _, _, _ = optimize.leastsq(lambda x: one(pair.from_internal(x)), x0, Dfun=jac, full_output=1, xtol=1e-7,
+                                         ftol=1e-7, gtol=1e-7, maxfev=2000 * (x0.size + 1), col_deriv=False)
+        return pair.from_internal(x)
+
+    def penalty(x):
+        r = one(pair.from_internal(x))
+        return float((r * r).sum())
+    sol = optimize.minimize(penalty, x0, method=scipy_name, options={'maxiter': 1000 * (x0.size + 1)})
+    return pair.from_internal(sol.x)
+
+
 def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='brute', percent_sigma=20., step=1.,
                         mode='O', n_points=200, bottom_type='B_bot', *, edp_builder, device=None, math=None):
     """Fit hmF2 and B_bot (or B0) of the F2 layer to an observed trace: the reference's ``minimize_parameters``
@@ -204,8 +318,15 @@ def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='br
     (:636-669: layer parameters written with ``np.full_like(F2['Nm'], ...)``, modeled NaNs replaced by
     ``max(nanmean|vh|, 100)``); the node with the smallest sum of squares wins (the first one on a tie:
     ``scipy.optimize.brute`` takes ``argmin`` of the grid, first parameter outermost); the final trace is
-    evaluated at the UNfiltered input frequencies (:821-824).  Only ``method='brute'`` exists here - the
-    reference's other methods are lmfit's own optimisers.
+    evaluated at the UNfiltered input frequencies (:821-824).
+
+    ``method``: the reference forwards the name to ``lmfit.minimize`` (:794-798).  ``'brute'`` (default) is the
+    batched grid search above.  Other names run what lmfit runs for them (``resolve_method``): Levenberg-Marquardt
+    (``'leastsq'``), ``'least_squares'``, the scalar minimisers (``'nelder'``, ``'powell'``, ``'lbfgsb'``, ``'cobyla'``,
+    ...; an unknown name such as the docstring's "levenberg-marquardt" is Nelder-Mead, as in lmfit) and
+    ``'differential_evolution'``, with lmfit's bounds transform and defaults restated from its documentation; every
+    residual they ask for is evaluated by the fused kernel, several at once where the algorithm allows it.  lmfit is
+    absent here, so the optimiser's path is parity-unpinned; the residuals are the pinned ones (G11).
     """
     from copy import deepcopy
 
@@ -215,8 +336,7 @@ def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='br
         raise ValueError('B0 and B1 are not provided in F, but bottom_type is B0_B1')              # :734-736
     if bottom_type not in ('B_bot', 'B0_B1'):
         raise ValueError("bottom_type must be 'B_bot' or 'B0_B1'")
-    if method != 'brute':
-        raise NotImplementedError("only method='brute' is batched here; the reference's other methods are lmfit's")
+    family, scipy_name = resolve_method(method)
     f_in0 = np.asarray(f_in0, dtype=np.float64)
     vh_obs0 = np.asarray(vh_obs0, dtype=np.float64)
     alt = np.asarray(alt, dtype=np.float64)
@@ -238,16 +358,31 @@ def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='br
         f2[second] = np.full_like(F2['Nm'], bb)
         return f2
 
-    nodes = [(hm, bb) for hm in hm_nodes for bb in bb_nodes]
-    den = np.empty((len(nodes), alt.size), dtype=np.float64)
-    for k, (hm, bb) in enumerate(nodes):
-        den[k] = np.asarray(edp_builder(layers(hm, bb), deepcopy(F1), deepcopy(E), alt, bottom_type), dtype=np.float64).ravel()
-    _, cost = residual_VH_batch(f_in, vh_obs, den, b_mag, b_psi, alt, mode, n_points, device=device, math=math)
-    finite = np.isfinite(cost)
-    if not finite.any():
-        raise ValueError("no node of the search grid produced a finite cost")
-    best = int(np.argmin(np.where(finite, cost, np.inf)))
-    F2_fit = layers(*nodes[best])
+    def candidates(nodes):
+        den = np.empty((len(nodes), alt.size), dtype=np.float64)
+        for k, (hm, bb) in enumerate(nodes):
+            den[k] = np.asarray(edp_builder(layers(hm, bb), deepcopy(F1), deepcopy(E), alt, bottom_type),
+                                dtype=np.float64).ravel()
+        return den
+
+    if family == 'brute':
+        nodes = [(hm, bb) for hm in hm_nodes for bb in bb_nodes]
+        _, cost = residual_VH_batch(f_in, vh_obs, candidates(nodes), b_mag, b_psi, alt, mode, n_points, device=device,
+                                    math=math)
+        finite = np.isfinite(cost)
+        if not finite.any():
+            raise ValueError("no node of the search grid produced a finite cost")
+        best = int(np.argmin(np.where(finite, cost, np.inf)))
+        F2_fit = layers(*nodes[best])
+    else:
+        sigma = float(percent_sigma) / 100.0
+        start = np.array([old_hmf2, float(np.asarray(F2[second]).squeeze())])
+        pair = BoundedPair(start, start * sigma)
+
+        def residuals(nodes):
+            return residual_VH_batch(f_in, vh_obs, candidates([tuple(v) for v in np.atleast_2d(nodes)]), b_mag, b_psi,
+                                     alt, mode, n_points, device=device, math=math, return_cost=False)
+        F2_fit = layers(*_local_search(residuals, pair, family, scipy_name))
     EDP_result = np.asarray(edp_builder(deepcopy(F2_fit), deepcopy(F1), deepcopy(E), alt, bottom_type), dtype=np.float64).ravel()
     from .library import vertical_forward_operator
     vh_result = vertical_forward_operator(f_in0, EDP_result, b_mag, b_psi, alt, mode, n_points, device=device, math=math)

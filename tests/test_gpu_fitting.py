@@ -223,8 +223,61 @@ def test_minimize_parameters_recovers_the_generating_layer(mode, n_points):
     with pytest.raises(ValueError, match="B0 and B1 are not provided"):
         fitting.minimize_parameters(F2_start, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, bottom_type='B0_B1',
                                     edp_builder=_chapman_builder)
-    with pytest.raises(NotImplementedError):
-        fitting.minimize_parameters(F2_start, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, 'powell', edp_builder=_chapman_builder)
+    with pytest.raises(NotImplementedError):              # lmfit's sampler is not restated (fitting.resolve_method)
+        fitting.minimize_parameters(F2_start, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, 'emcee', edp_builder=_chapman_builder)
+
+
+@pytest.mark.parametrize("method,tol_km", [("leastsq", None), ("least_squares", None), ("powell", 1e-2),
+                                           ("levenberg-marquardt", None), ("lbfgsb", None),
+                                           ("differential_evolution", 1e-2)])
+def test_minimize_parameters_other_lmfit_methods(method, tol_km):
+    """The reference forwards `method` to lmfit.minimize (library.py:794-798): the local and population optimisers lmfit
+    runs for those names (restated, fitting.resolve_method), every residual evaluated by the fused kernel - the
+    forward-difference Jacobian of Levenberg-Marquardt and a generation of differential evolution as one launch each.
+    The cost surface is the reference's: the bottomside ends at the level below the density peak (library.py:371-375),
+    so the trace near foF2 jumps whenever hmF2 crosses half a level, and a gradient search stops at the first such
+    step (which is why the reference's default is the grid search).  Asked of every method: a lower cost than the
+    start, inside the bounds; of Powell's line searches and of differential evolution: the generating layer."""
+    from pyrayhf_amd import fitting, library
+    alt = np.arange(80.0, 500.0, 1.0)
+    b_mag = 4.6e-5 * ((6371.0 + 80.0) / (6371.0 + alt)) ** 3
+    b_psi = 35.0 + 0.002 * (alt - alt[0])
+    f_in0 = np.arange(1.5, 9.6, 0.25)
+    nm_true = fitting.peak_density_from_trace(f_in0[-1], "X", alt=alt, bmag=b_mag, hmf2=304.0)
+    F2_true, F1, E = _layer_dicts(nm_true, 300.5, 46.0)
+    truth = _chapman_builder(F2_true, F1, E, alt, 'B_bot')
+    vh_obs0 = library.vertical_forward_operator(f_in0, truth, b_mag, b_psi, alt, "X", 200)
+    assert np.isfinite(vh_obs0).all()
+    F2_start, _, _ = _layer_dicts(1.0e12, 304.0, 44.0)
+    calls = []
+    real = fitting.residual_VH_batch
+
+    def counting(*a, **k):
+        calls.append(np.atleast_2d(a[2]).shape[0])
+        return real(*a, **k)
+    fitting.residual_VH_batch = counting
+    try:
+        vh, edp, F2_fit = fitting.minimize_parameters(F2_start, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method, 20.0,
+                                                      1.0, "X", 200, 'B_bot', edp_builder=_chapman_builder)
+    finally:
+        fitting.residual_VH_batch = real
+    hm, bb = float(F2_fit['hm'].squeeze()), float(F2_fit['B_bot'].squeeze())
+    assert 304.0 * 0.8 <= hm <= 304.0 * 1.2 and 44.0 * 0.8 <= bb <= 44.0 * 1.2
+    assert float(F2_fit['Nm'].squeeze()) == nm_true
+    start_edp = _chapman_builder(_layer_dicts(nm_true, 304.0, 44.0)[0], F1, E, alt, 'B_bot')
+    _, cost = fitting.residual_VH_batch(f_in0, vh_obs0, np.stack([start_edp, edp]), b_mag, b_psi, alt, "X", 200)
+    assert cost[1] < cost[0], (method, hm, bb, cost)
+    if tol_km is not None:
+        assert abs(hm - 300.5) < tol_km and abs(bb - 46.0) < tol_km, (method, hm, bb)
+        assert np.nanmax(np.abs(vh - vh_obs0)) < 1.0
+    assert F2_fit['hm'].shape == F2_start['Nm'].shape and vh.shape == f_in0.shape and edp.shape == alt.shape
+    assert float(F2_start['hm'].squeeze()) == 304.0
+    if method == "leastsq":
+        assert 3 in calls                                  # f(x) and the two forward steps of the Jacobian: one launch
+    if method == "differential_evolution":
+        assert max(calls) >= 30                            # a generation (15 x 2 members) at a time
+    print(f"{method}: hmF2 {hm:.6f}, B_bot {bb:.6f}, cost {cost[0]:.4g} -> {cost[1]:.4g}, {len(calls)} launches, "
+          f"{sum(calls)} residual rows")
 
 
 def test_residual_batch_on_gpu_resident_candidates():

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Short-grid O kernel, compact geometry: workgroups per CU (builds with -DPRHF_COMPACT_WGS_PER_CU=n), same box, one
+child per library.  The workload is config 3's shape restricted to profiles whose peak lies below level `--kmax`
+(default 270), so that every setting's staged arrays hold every bottomside and nothing goes to the second launch.
+    python tools/ab_short_wgs.py lib4.so lib5.so ...      ('-' = the in-tree build)"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+KMAX = 270
+
+def child(tag):
+    import torch
+    from pyrayhf_amd import library, synth, _native
+    dev = torch.device("cuda", 0)
+    ctx = _native.context(0)
+    alt, den, bmag, bpsi = synth.chapman_profiles(16000, 20260003)
+    keep = np.nonzero(np.argmax(den, axis=1) < KMAX)[0][:5000]
+    assert keep.size == 5000
+    keep = np.concatenate([keep, keep])                      # 10 000 rows: ten resident rounds, as config 3
+    den, bmag, bpsi = den[keep], bmag[keep], bpsi[keep]
+    res = {"tag": tag, "rows": int(keep.size), "k_max": int(np.argmax(den, axis=1).max())}
+    for name, freq, n in (("o200_f174", synth.sounder_frequencies(1), 200), ("o500_f174", synth.sounder_frequencies(1), 500)):
+        t = [torch.as_tensor(x, device=dev) for x in (freq, den, bmag, bpsi, alt)]
+        ms = []
+        for r in range(14):
+            out = library.vertical_forward_operator(*t, "O", n, sync=True)
+            if r >= 2:
+                ms.append(ctx.last_kernel_ms())
+        res[name] = round(float(np.median(ms)), 4)
+        np.save(os.path.join(ROOT, "gpurun_out", f"wgs_{tag}_{name}.npy"), out.cpu().numpy())
+    print(json.dumps(res), flush=True)
+
+if len(sys.argv) > 2 and sys.argv[1] == "--child":
+    child(sys.argv[2])
+    sys.exit(0)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+for i, lib in enumerate(sys.argv[1:]):
+    env = dict(os.environ)
+    if lib != "-":
+        env["PRHF_LIB"] = os.path.abspath(lib)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f"s{i}"], env=env, check=True,
+                         capture_output=True, text=True).stdout
+    r = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    r["lib"] = lib
+    for name in ("o200_f174", "o500_f174"):
+        a = np.load(os.path.join(ROOT, "gpurun_out", f"wgs_s0_{name}.npy"))
+        b = np.load(os.path.join(ROOT, "gpurun_out", f"wgs_s{i}_{name}.npy"))
+        r[name + "_same"] = bool(np.array_equal(a, b, equal_nan=True))
+    print(json.dumps(r), flush=True)
+for f in os.listdir(os.path.join(ROOT, "gpurun_out")):
+    if f.startswith("wgs_") and f.endswith(".npy"):
+        os.remove(os.path.join(ROOT, "gpurun_out", f))
