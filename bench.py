@@ -321,6 +321,16 @@ def main():
         else:
             dist.init_process_group(backend)
     world_seen = dist.get_world_size() if collective else 1
+    if collective:
+        # Communicator set-up (RCCL builds its rings and its send/recv channels on first use: seconds) belongs to the
+        # environment, not to a step: one tiny exchange of each kind the steps use, whatever --warmup is.
+        side0 = dev if backend == "nccl" else torch.device("cpu")
+        tiny = torch.zeros((1, 8), dtype=torch.float64, device=side0)
+        pdist._exchange(tiny, world_seen, None, None)
+        pdist._exchange(tiny, world_seen, None, 0)
+        if backend == "nccl":
+            torch.cuda.synchronize(dev)
+        dist.barrier()
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
     ctx = _native.context(local_rank)
