@@ -83,6 +83,9 @@ struct Knobs {
                                        // another (1: one upload, one launch, one download)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
+    double snell_table = 2;            // tracers: the frequency-independent parts of every level's mu, mu' (f_N^2, g_p |B|,
+                                       // sin psi, cos psi) once per profile when the rays (groups) number at least this
+                                       // many times the profiles (0: never; values do not depend on it)
 };
 struct KnobName {
     const char* name;
@@ -112,6 +115,7 @@ const KnobName kKnobNames[] = {
     {"short_prio", &Knobs::short_prio, 0, 3},
     {"host_slabs", &Knobs::host_slabs, 1, 3},
     {"short_order", &Knobs::short_order, 0, 1},
+    {"snell_table", &Knobs::snell_table, 0, 1e9},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -199,6 +203,7 @@ struct prhf_ctx {
     DevBuf pairs;     // (m_i, m_i+1 - m_i) table of the fast tier's main loop
     DevBuf ftab;      // per-frequency scalars of a long launch
     DevBuf levels;    // level table of a grouped tracer launch
+    DevBuf ptab;      // tracers: per-profile table of the frequency-independent parts of a level's mu, mu'
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
     DevBuf leftover_tall;   // compact short-grid launch: the profiles whose bottomside needs the full-size arrays
@@ -1099,6 +1104,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->pairs.p) (void)hipFree(c->pairs.p);
     if (c->ftab.p) (void)hipFree(c->ftab.p);
     if (c->levels.p) (void)hipFree(c->levels.p);
+    if (c->ptab.p) (void)hipFree(c->ptab.p);
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
     if (c->leftover_tall.p) (void)hipFree(c->leftover_tall.p);
@@ -1503,6 +1509,12 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         if (rc2 != PRHF_OK) return rc2;
         a.prof_info = static_cast<double*>(c->partial.p);
         a.n_prof = n_prof;
+    }
+    a.ptab = nullptr;
+    if (c->knobs.snell_table > 0 && (double)n_keys >= c->knobs.snell_table * (double)n_prof) {
+        int rc4 = ensure(c, c->ptab, prof_elems * 32);
+        if (rc4 != PRHF_OK) return rc4;
+        a.ptab = static_cast<double*>(c->ptab.p);
     }
     HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     HIP_TRY(prhf::launch_snell(a, c->stream));

@@ -241,6 +241,11 @@ struct SnellArgs {
     unsigned* ray_queue;
     int resident_cus;            // multiprocessors of the device (sizes the persistent grid)
     double* prof_info;           // (n_prof, 2) scratch: max|B| and "has a negative density", filled by launch_snell
+    // Per-profile level table (or null), filled by launch_snell: what a level's mu and mu' need that does not depend on
+    // the frequency - f_N^2 = (sqrt(den) c_p)^2, g_p |B|, sin(psi), cos(psi) - so that a ray pays two quotients and
+    // the Appleton-Hartree algebra per level instead of a square root and a correctly rounded sine / cosine on top
+    // (the same operations on the same values: bit-identical).  Worth it when the rays outnumber the profiles.
+    double* ptab;                // (n_prof, n_alt, 4)
     long long n_prof;
     double* out;                 // (n_rays, PRHF_SNELL_OUTPUTS)
     double* path_x;              // (n_rays, path_stride) or null
@@ -256,7 +261,7 @@ struct SnellArgs {
 };
 hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
 // wavefronts of the per-ray kernel that one device keeps resident; cu_count: multiprocessors of the device
-hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves);
+hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false);
 
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,

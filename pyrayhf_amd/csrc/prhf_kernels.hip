@@ -188,17 +188,26 @@ __device__ __forceinline__ double rsqrt_tier(double x) {
 // ---------------------------------------------------------------------------------------
 // Appleton-Hartree group index, reference operation order (library.py:194-256).
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void index_faithful(double X, double Y, double psi_deg, double* mu_out,
-                                               double* mup_out) {
+// sin and cos of a field angle given in degrees, rounded the way the reference's libm rounds them (prhf_crmath.h)
+__device__ __forceinline__ void faithful_sincos(double psi_deg, double* s_out, double* c_out) {
 #pragma clang fp contract(off)
-    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;   // library.py:221-224
     const double r = psi_deg * kDegToRad;
     double s, c;
-    // sin, cos, YT**4 and YT**3 rounded the way the reference's libm / NumPy pow round them (prhf_crmath.h):
-    // near reflection D cancels to 1e-9 of its terms and these roundings decide the last grid points
     if (__builtin_fabs(r) < 1.0e6) prhf_cr::sincos_table(r, &s, &c);
     else sincos(r, &s, &c);
+    *s_out = s;
+    *c_out = c;
+}
+
+// ... from sin(psi) and cos(psi) (faithful_sincos): callers that evaluate many frequencies on the same levels compute
+// those once per level (the tracers' per-profile table, prhf_snell.inc)
+template <int MODE>
+__device__ __forceinline__ void index_faithful_sc(double X, double Y, double s, double c, double* mu_out,
+                                                  double* mup_out) {
+#pragma clang fp contract(off)
+    constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;   // library.py:221-224
+    // sin, cos, YT**4 and YT**3 rounded the way the reference's libm / NumPy pow round them (prhf_crmath.h):
+    // near reflection D cancels to 1e-9 of its terms and these roundings decide the last grid points
     const double YT = Y * s;                                   // :210
     const double YL = Y * c;                                   // :211
     const double Xm1 = 1.0 - X;                                // :214
@@ -224,6 +233,14 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
     const double dmudX = (1.0 / (two_mu * D)) * (((2.0 * X) - 1.0) + q * dDdX);   // :251
     *mu_out = mu;
     *mup_out = mu - ((2.0 * X) * dmudX + Y * dmudY);           // :254
+}
+
+template <int MODE>
+__device__ __forceinline__ void index_faithful(double X, double Y, double psi_deg, double* mu_out,
+                                               double* mup_out) {
+    double s, c;
+    faithful_sincos(psi_deg, &s, &c);
+    index_faithful_sc<MODE>(X, Y, s, c, mu_out, mup_out);
 }
 
 // The same mu and mu' in reduced form.  With S2 = sin^2 psi, Y2 = Y^2, a = 1 - X, s = +1 (O) / -1 (X):

@@ -173,3 +173,44 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
     one = tracers.trace_fan_cartesian_snells(np.array([5e6, 7e6]), np.array([20.0, 60.0, 80.0]), g["gauss_alt"],
                                              two[0][1], two[1][1], two[2][1], "O")
     assert np.array_equal(fan["group_path_km"][1], one["group_path_km"], equal_nan=True)
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_per_profile_level_table_changes_no_bit(spherical):
+    """Option snell_table: f_N^2, g_p |B|, sin(psi), cos(psi) of every level once per profile (snell_profile_kernel)
+    instead of per ray and level - hoisted, not changed: the rays of the per-ray call, of the grouped call and their
+    paths come out bit for bit the same with the table (default when the rays outnumber the profiles two to one),
+    without it (0) and with it forced on a launch that would not take it (1 ray per profile)."""
+    from pyrayhf_amd import library, synth, tracers
+    alt, den, bmag, bpsi = synth.chapman_profiles(24, 77)
+    bmag[3] = 0.0                                            # an unmagnetised column (library.py:201-207)
+    rng = np.random.default_rng(5)
+    n = 600
+    f = rng.uniform(2e6, 14e6, n)
+    e = rng.uniform(3.0, 90.0, n)
+    idx = rng.integers(0, 24, n)
+    ray_fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+    fan_fn = tracers.trace_fan_spherical_snells if spherical else tracers.trace_fan_cartesian_snells
+    keys = ("group_path_km", "group_delay_sec", "ground_range_km", "x_turn_km", "z_turn_km", "x_midpoint", "z_midpoint",
+            "n_path", "x", "z")
+    try:
+        for mode in "OX":
+            got = {}
+            for setting in (2.0, 0.0):
+                library.set_option("snell_table", setting)
+                got[setting] = (ray_fn(f, e, alt, den, bmag, bpsi, mode, profile_index=idx, return_paths=True),
+                                fan_fn(np.array([3e6, 6e6, 9e6, 12e6]), np.array([10.0, 45.0, 80.0]), alt, den[:5], bmag[:5],
+                                       bpsi[:5], mode, return_paths=True))
+            for a, b in zip(got[2.0], got[0.0]):
+                for key in keys:
+                    assert np.array_equal(a[key], b[key], equal_nan=True), (mode, key)
+            assert np.isfinite(got[2.0][0]["group_path_km"]).sum() > 100
+            # one ray per profile: not worth a table by default (24 rays < 2 x 24 profiles); forced, the same bits
+            few = {}
+            for setting in (2.0, 1.0):
+                library.set_option("snell_table", setting)
+                few[setting] = ray_fn(f[:24], e[:24], alt, den, bmag, bpsi, mode, profile_index=np.arange(24))
+            for key in keys[:7]:
+                assert np.array_equal(few[2.0][key], few[1.0][key], equal_nan=True), (mode, key)
+    finally:
+        library.set_option("snell_table", 2.0)

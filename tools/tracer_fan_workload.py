@@ -5,6 +5,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyrayhf_amd import tracers, synth, _native
+import _options
+opts = _options.apply()                 # PRHF_TOOL_OPTIONS="name=value,..."
 
 P, F, E = 16, 100, 128
 alt, den, bmag, bpsi = synth.chapman_profiles(P, 7)

@@ -5,6 +5,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyrayhf_amd import tracers, synth, _native
+import _options
+opts = _options.apply()                 # PRHF_TOOL_OPTIONS="name=value,..."
 
 alt, den, bmag, bpsi = synth.chapman_profiles(256, 7)
 rng = np.random.default_rng(0)
@@ -16,4 +18,4 @@ for name, fn in (("cartesian", tracers.trace_rays_cartesian_snells), ("spherical
         r = fn(f, e, alt, den, bmag, bpsi, "O", profile_index=idx)
     kms = ctx.last_kernel_ms()
     print(json.dumps({"tracer": name, "rays": R, "traced_fraction": float(np.isfinite(r["group_path_km"]).mean()),
-                      "kernel_ms": kms, "rays_per_s_kernel": R / (kms * 1e-3)}), flush=True)
+                      "options": opts, "kernel_ms": kms, "rays_per_s_kernel": R / (kms * 1e-3)}), flush=True)
