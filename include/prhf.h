@@ -120,7 +120,7 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *                        bottomside of the launch fits LDS, only the levels up to the highest peak are staged)
  *   "snell_table"        tracers: the frequency-independent parts of a level's mu, mu' (f_N^2, g_p |B|, sin psi, cos psi)
  *                        are tabulated once per profile when the rays (groups) number at least this many times the
- *                        profiles (2; 0: never) */
+ *                        profiles and the table stays under 1 GiB (4; 0: never) */
 int prhf_ctx_set_option(prhf_ctx* ctx, const char* name, double value);
 
 /*

@@ -83,9 +83,11 @@ struct Knobs {
                                        // another (1: one upload, one launch, one download)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
-    double snell_table = 2;            // tracers: the frequency-independent parts of every level's mu, mu' (f_N^2, g_p |B|,
+    double snell_table = 4;            // tracers: the frequency-independent parts of every level's mu, mu' (f_N^2, g_p |B|,
                                        // sin psi, cos psi) once per profile when the rays (groups) number at least this
-                                       // many times the profiles (0: never; values do not depend on it)
+                                       // many times the profiles - a ray stops at its turning point, after a third to a
+                                       // half of the column, the table covers all of it - and the table stays under
+                                       // 1 GiB (0: never; values do not depend on it)
 };
 struct KnobName {
     const char* name;
@@ -1511,7 +1513,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         a.n_prof = n_prof;
     }
     a.ptab = nullptr;
-    if (c->knobs.snell_table > 0 && (double)n_keys >= c->knobs.snell_table * (double)n_prof) {
+    if (c->knobs.snell_table > 0 && (double)n_keys >= c->knobs.snell_table * (double)n_prof && prof_elems * 32 <= ((size_t)1 << 30)) {
         int rc4 = ensure(c, c->ptab, prof_elems * 32);
         if (rc4 != PRHF_OK) return rc4;
         a.ptab = static_cast<double*>(c->ptab.p);

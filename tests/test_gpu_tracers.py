@@ -179,7 +179,7 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
 def test_per_profile_level_table_changes_no_bit(spherical):
     """Option snell_table: f_N^2, g_p |B|, sin(psi), cos(psi) of every level once per profile (snell_profile_kernel)
     instead of per ray and level - hoisted, not changed: the rays of the per-ray call, of the grouped call and their
-    paths come out bit for bit the same with the table (default when the rays outnumber the profiles two to one),
+    paths come out bit for bit the same with the table (default when the rays outnumber the profiles four to one),
     without it (0) and with it forced on a launch that would not take it (1 ray per profile)."""
     from pyrayhf_amd import library, synth, tracers
     alt, den, bmag, bpsi = synth.chapman_profiles(24, 77)
@@ -196,21 +196,21 @@ def test_per_profile_level_table_changes_no_bit(spherical):
     try:
         for mode in "OX":
             got = {}
-            for setting in (2.0, 0.0):
+            for setting in (4.0, 0.0):
                 library.set_option("snell_table", setting)
                 got[setting] = (ray_fn(f, e, alt, den, bmag, bpsi, mode, profile_index=idx, return_paths=True),
                                 fan_fn(np.array([3e6, 6e6, 9e6, 12e6]), np.array([10.0, 45.0, 80.0]), alt, den[:5], bmag[:5],
                                        bpsi[:5], mode, return_paths=True))
-            for a, b in zip(got[2.0], got[0.0]):
+            for a, b in zip(got[4.0], got[0.0]):
                 for key in keys:
                     assert np.array_equal(a[key], b[key], equal_nan=True), (mode, key)
-            assert np.isfinite(got[2.0][0]["group_path_km"]).sum() > 100
-            # one ray per profile: not worth a table by default (24 rays < 2 x 24 profiles); forced, the same bits
+            assert np.isfinite(got[4.0][0]["group_path_km"]).sum() > 100
+            # one ray per profile: not worth a table by default (24 rays < 4 x 24 profiles); forced, the same bits
             few = {}
-            for setting in (2.0, 1.0):
+            for setting in (4.0, 1.0):
                 library.set_option("snell_table", setting)
                 few[setting] = ray_fn(f[:24], e[:24], alt, den, bmag, bpsi, mode, profile_index=np.arange(24))
             for key in keys[:7]:
-                assert np.array_equal(few[2.0][key], few[1.0][key], equal_nan=True), (mode, key)
+                assert np.array_equal(few[4.0][key], few[1.0][key], equal_nan=True), (mode, key)
     finally:
-        library.set_option("snell_table", 2.0)
+        library.set_option("snell_table", 4.0)
