@@ -262,7 +262,13 @@ def _local_search(residuals, pair, family, scipy_name):
     from scipy import optimize
 
     def one(v):
-        return residuals(np.asarray(v, dtype=np.float64).reshape(1, 2))[0]
+        r = residuals(np.asarray(v, dtype=np.float64).reshape(1, 2))[0]
+        if not np.isfinite(r).all():
+            # lmfit's nan_policy='raise' (its default): a candidate none of whose frequencies reflects gives an all-NaN
+            # residual row (library.py:664-665: np.maximum(nanmean of nothing, 100) is NaN)
+            raise ValueError("NaN values detected in the output of the residual function: the optimisers cannot handle "
+                             "this (lmfit's nan_policy='raise')")
+        return r
 
     if family == 'least_squares':                          # bounds as they are, no transform (lmfit.least_squares)
         sol = optimize.least_squares(one, pair.value, bounds=(pair.lo, pair.hi))

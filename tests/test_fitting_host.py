@@ -63,3 +63,13 @@ def test_every_optimiser_family_finds_the_minimum_of_a_synthetic_trace(family, n
         assert set(batches) == {1, 3}                     # single evaluations and Jacobian batches of n + 1 rows
     if family == "differential_evolution":
         assert max(batches) >= 30
+
+
+def test_a_nan_residual_raises_as_lmfit_does_by_default():
+    pair = fitting.BoundedPair([300.0, 40.0], [60.0, 8.0])
+
+    def residuals(nodes):
+        return np.full((np.atleast_2d(nodes).shape[0], 5), np.nan)
+    for family, name in (("leastsq", None), ("least_squares", None), ("scalar", "Powell")):
+        with pytest.raises(ValueError, match="NaN values detected"):
+            fitting._local_search(residuals, pair, family, name)
