@@ -199,6 +199,31 @@ __device__ __forceinline__ void faithful_sincos(double psi_deg, double* s_out, d
     *c_out = c;
 }
 
+// sin^2 of an angle given in degrees for the REDUCED algebra (index_fast), to 2e-16 absolute - the reference's order
+// takes faithful_sincos.  r = n pi/2 + y with |y| <= pi/4 (two-piece Cody-Waite reduction, exact enough up to |r| = 1e5);
+// sin^2 r is sin^2 y for even n and 1 - sin^2 y for odd n, so one odd polynomial (fdlibm's kernel_sin coefficients,
+// 2^-58 on that interval) serves every quadrant: ~22 instructions for the device library's ~90.
+__device__ __forceinline__ double sin_sq_deg(double psi_deg) {
+#pragma clang fp contract(fast)
+    const double r = psi_deg * kDegToRad;
+    if (!(__builtin_fabs(r) < 1.0e5)) {                // (never a field angle; NaN comes through here as NaN)
+        const double sl = sin(r);
+        return sl * sl;
+    }
+    const double n = __builtin_rint(r * 0.6366197723675814);
+    double y = __builtin_fma(-n, 1.5707963267948966, r);
+    y = __builtin_fma(-n, 6.123233995736766e-17, y);
+    const double z = y * y;
+    double p = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    p = __builtin_fma(z, p, 2.75573137070700676789e-06);
+    p = __builtin_fma(z, p, -1.98412698298579493134e-04);
+    p = __builtin_fma(z, p, 8.33333333332248946124e-03);
+    p = __builtin_fma(z, p, -1.66666666666666324348e-01);
+    const double sy = __builtin_fma(y * z, p, y);
+    const double s2 = sy * sy;
+    return ((int)n & 1) ? 1.0 - s2 : s2;
+}
+
 // ... from sin(psi) and cos(psi) (faithful_sincos): callers that evaluate many frequencies on the same levels compute
 // those once per level (the tracers' per-profile table, prhf_snell.inc)
 template <int MODE>
@@ -745,8 +770,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             if (__all(1.0 - Xq > well_conditioned)) {
 #pragma clang fp contract(fast)
                 const double b = sb_ * dz + nd.b;
-                const double sn = sin((spsi_ * dz + nd.psi) * kDegToRad);
-                index_fast<MODE>(Xq, (b * b) * cY2, sn * sn, &mu, &mup);
+                index_fast<MODE>(Xq, (b * b) * cY2, sin_sq_deg(spsi_ * dz + nd.psi), &mu, &mup);
                 return mup;
             }
         }
@@ -773,8 +797,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
             if (poly_angle || nd.u3 == nd.u3) {        // per segment; poly_angle: true for the whole profile
                 S2 = 1.0 - 0.5 * (nd.u0 + dz * (nd.u1 + dz * (nd.u2 + dz * nd.u3)));    // the nodes hold 2 cos^2
             } else {
-                const double sn = sin((spsi_ * dz + nd.psi) * kDegToRad);
-                S2 = sn * sn;
+                S2 = sin_sq_deg(spsi_ * dz + nd.psi);
             }
             index_fast<MODE>(X, Y2, S2, &mu, &mup);
         }
@@ -2073,9 +2096,9 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
             if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(x, y, p, mu, mup);
             else index_faithful<PRHF_KMODE_X>(x, y, p, mu, mup);
         } else {
-            const double sn = sin(p * kDegToRad);
-            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, sn * sn, mu, mup);
-            else index_fast<PRHF_KMODE_X>(x, y * y, sn * sn, mu, mup);
+            const double s2 = sin_sq_deg(p);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, s2, mu, mup);
+            else index_fast<PRHF_KMODE_X>(x, y * y, s2, mu, mup);
         }
     };
     // two elements per thread and pass where the five arrays allow 16-byte accesses (wider loads in flight, half
@@ -2196,9 +2219,9 @@ __global__ void find_vh_kernel(const double* __restrict__ X, const double* __res
             if (mode == PRHF_KMODE_O) index_faithful<PRHF_KMODE_O>(x, y, p, &mu, &mup);
             else index_faithful<PRHF_KMODE_X>(x, y, p, &mu, &mup);
         } else {
-            const double sn = sin(p * kDegToRad);
-            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, sn * sn, &mu, &mup);
-            else index_fast<PRHF_KMODE_X>(x, y * y, sn * sn, &mu, &mup);
+            const double s2 = sin_sq_deg(p);
+            if (mode == PRHF_KMODE_O) index_fast<PRHF_KMODE_O>(x, y * y, s2, &mu, &mup);
+            else index_fast<PRHF_KMODE_X>(x, y * y, s2, &mu, &mup);
         }
         const double term = mup * thickness;                   // :288
         if (term == term) acc = acc + term;
