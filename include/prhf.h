@@ -118,6 +118,8 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *   "timing"             1: synchronous host-buffer operator calls record timing events too (0; see prhf_last_kernel_ms)
  *   "trim_lds"           0: a column of more than 1400 levels is always staged in global memory (1: when every
  *                        bottomside of the launch fits LDS, only the levels up to the highest peak are staged)
+ *   "tall_lean"          0: a profile staged in global memory takes the generic loop (1: the main loop reads its nodes
+ *                        from the slab)
  *   "snell_table"        tracers: the frequency-independent parts of a level's mu, mu' (f_N^2, g_p |B|, sin psi, cos psi)
  *                        are tabulated once per profile when the rays (groups) number at least this many times the
  *                        profiles and the table stays under 1 GiB (4; 0: never) */

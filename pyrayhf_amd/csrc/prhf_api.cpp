@@ -83,6 +83,8 @@ struct Knobs {
                                        // another (1: one upload, one launch, one download)
     double local_chunks = 1;           // few-pair launches: a pair's chunks are waves of ONE workgroup, which adds them up
                                        // itself (0: chunks anywhere in the launch, sums through scratch + vfo_finalize_kernel)
+    double tall_lean = 1;              // profiles staged in global memory (more than 1400 levels below the highest peak): the
+                                       // main loop on the slab's nodes (0: the generic loop)
     double snell_table = 4;            // tracers: the frequency-independent parts of every level's mu, mu' (f_N^2, g_p |B|,
                                        // sin psi, cos psi) once per profile when the rays (groups) number at least this
                                        // many times the profiles - a ray stops at its turning point, after a third to a
@@ -118,6 +120,7 @@ const KnobName kKnobNames[] = {
     {"host_slabs", &Knobs::host_slabs, 1, 3},
     {"short_order", &Knobs::short_order, 0, 1},
     {"snell_table", &Knobs::snell_table, 0, 1e9},
+    {"tall_lean", &Knobs::tall_lean, 0, 1},
 };
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
@@ -492,8 +495,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         const long long seg_pairs = (u.prof_end - u.prof_begin) * n_freq;
         // (decided from the slice's shape alone: host and device callers must get the same arithmetic)
         const bool table_is_cheap = seg_pairs >= 4096 || u.n_points >= 2048;
-        s.lean = (!tall && (s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints && seg_pairs > 0 &&
-                  table_is_cheap) ? 1 : 0;
+        // (a profile staged in global memory - `tall` - takes the main loop too: it reads the nodes from the workgroup's
+        //  slab through a buffer resource, NodeSpace<true>; option tall_lean = 0: the generic loop, as up to round 4)
+        s.lean = ((!tall || kn.tall_lean != 0) && (s.tier == 1 || s.well_conditioned < 1.0) && u.n_points >= kLeanMinPoints &&
+                  seg_pairs > 0 && table_is_cheap) ? 1 : 0;
         want_pairs = want_pairs || s.lean != 0;
         s.thread_scan = (!tall && (double)n_freq * (double)u.n_points >= kThreadScanMinWork) ? 1 : 0;
         plan_slice(s, n_freq, wg_slots, kn);

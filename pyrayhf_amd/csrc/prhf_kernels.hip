@@ -862,13 +862,51 @@ struct SegCursor {
     int j;
     double above;       // nodes[j + 1].alt; level K is a +inf sentinel, so a walk stops by itself
 };
-__device__ __forceinline__ double lds_alt(unsigned nodes_v, int j) {
-    typedef __attribute__((address_space(3))) const double* LdsDouble;
-    return *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
+// Where the main loop finds a staged profile's nodes: in LDS (G = false: a 32-bit LDS byte address, kept in a VGPR) or -
+// a profile with more levels than LDS holds (vfo_tall_kernel) - in the workgroup's slab of global memory (G = true),
+// read through a buffer resource with the byte offset in a VGPR, like the pair table: the same one vector instruction
+// per node address either way.  The loop is the same; what differs is the latency it has to cover.
+typedef double node_vec2 __attribute__((ext_vector_type(2)));
+template <bool G> struct NodeSpace;
+template <> struct NodeSpace<false> {
+    unsigned base;
+    __device__ __forceinline__ double f64(unsigned off) const {
+        typedef __attribute__((address_space(3))) const double* LdsDouble;
+        return *(LdsDouble)(uintptr_t)(base + off);
+    }
+    __device__ __forceinline__ node_vec2 v2(unsigned off) const {
+        typedef __attribute__((address_space(3))) const node_vec2* LdsVec2;
+        return *(LdsVec2)(uintptr_t)(base + off);
+    }
+};
+template <> struct NodeSpace<true> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ double f64(unsigned off) const {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        double d;
+        __builtin_memcpy(&d, &v, sizeof d);
+        return d;
+    }
+    __device__ __forceinline__ node_vec2 v2(unsigned off) const {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        node_vec2 d;
+        __builtin_memcpy(&d, &v, sizeof d);
+        return d;
+    }
+};
+// the argument that names the nodes across the (not inlined) loop function: an LDS address or a pointer
+template <bool G> struct NodeArg { typedef unsigned type; };
+template <> struct NodeArg<true> { typedef const Node* type; };
+template <bool G>
+__device__ __forceinline__ double lds_alt(const NodeSpace<G>& ns, int j) {
+    return ns.f64(__umul24((unsigned)j, (unsigned)sizeof(Node)));
 }
 // np.interp's segment of abscissa z = m span + a0 from the hint table (last level at or below the bucket's left edge)
 // plus a walk up the levels inside the bucket: once per loop call and lane
-__device__ __forceinline__ SegCursor cursor_at(double m0, double span, double a0, double kj, unsigned nodes_v, unsigned hint_v) {
+template <bool G>
+__device__ __forceinline__ SegCursor cursor_at(double m0, double span, double a0, double kj, const NodeSpace<G>& nodes_v, unsigned hint_v) {
 #pragma clang fp contract(fast)
     typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
     SegCursor c;
@@ -885,16 +923,13 @@ __device__ __forceinline__ SegCursor cursor_at(double m0, double span, double a0
     return c;
 }
 
-template <int MODE, bool CHECK, int POLY, bool HINT>
+template <int MODE, bool CHECK, int POLY, bool HINT, bool G>
 __device__ __forceinline__ double lean_step(double2 g, double span, double a0, double kj, double cX,
                                             double hcY2, double acc, double wc, unsigned long long& viol,
-                                            unsigned nodes_v, SegCursor& cur) {
+                                            const NodeSpace<G>& nodes_v, SegCursor& cur) {
 #pragma clang fp contract(fast)
     const double m0 = g.x;
-    typedef __attribute__((address_space(3))) const char* LdsBytes;
-    typedef __attribute__((address_space(3))) const double* LdsDouble;
-    typedef double vec2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) const vec2* LdsVec2;
+    typedef node_vec2 vec2;
     int j;
     if (HINT) {
         const double z = __builtin_fma(m0, span, a0);
@@ -914,13 +949,13 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
         // next to 2^52.)
         j = (int)(m0 * kj);
     }
-    const LdsBytes pn = (LdsBytes)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
-    double off = *(LdsDouble)(pn + 8);
-    const vec2 r_dd = *(LdsVec2)(pn + 16), r_bb = *(LdsVec2)(pn + 32), r_ua = *(LdsVec2)(pn + 48);
+    const unsigned pn = __umul24((unsigned)j, (unsigned)sizeof(Node));
+    double off = nodes_v.f64(pn + 8);
+    const vec2 r_dd = nodes_v.v2(pn + 16), r_bb = nodes_v.v2(pn + 32), r_ua = nodes_v.v2(pn + 48);
     vec2 r_ub;
     if (POLY == 1) { r_ub.x = 0.0; r_ub.y = 0.0; }
-    else if (POLY == 2 || POLY == 4) { r_ub.x = *(LdsDouble)(pn + 64); r_ub.y = 0.0; }
-    else r_ub = *(LdsVec2)(pn + 64);
+    else if (POLY == 2 || POLY == 4) { r_ub.x = nodes_v.f64(pn + 64); r_ub.y = 0.0; }
+    else r_ub = nodes_v.v2(pn + 64);
     double2 dd = make_double2(r_dd.x, r_dd.y);                     // den, sden
     double2 bb = make_double2(r_bb.x, r_bb.y);                     // b, sb
     double2 ua = make_double2(r_ua.x, r_ua.y);                     // u0, u1
@@ -962,13 +997,14 @@ struct TopSegment {
     double b0, b1;          // Y / sqrt(2) = g_p |B| / (sqrt(2) f) = b0 + b1 m
     double q0, q1, q2, q3;  // 2 cos^2 psi = q0 + m (q1 + m (q2 + m q3))
 };
-__device__ __forceinline__ TopSegment top_segment(unsigned nodes_v, int j, double span, double cY) {
+template <bool G>
+__device__ __forceinline__ TopSegment top_segment(const NodeSpace<G>& nodes_v, int j, double span, double cY) {
 #pragma clang fp contract(fast)
-    typedef __attribute__((address_space(3))) const double* LdsDouble;
-    const LdsDouble nd = (LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)));
+    const unsigned nd = __umul24((unsigned)j, (unsigned)sizeof(Node));
     // Node = {alt, off, den, sden, b, sb, u0, u1, u2, u3, psi, spsi}
-    const double o = nd[1], s = span;                          // x = s m + o
-    const double den = nd[2], sden = nd[3], b = nd[4], sb = nd[5], u0 = nd[6], u1 = nd[7], u2 = nd[8], u3 = nd[9];
+    const double o = nodes_v.f64(nd + 8), s = span;            // x = s m + o
+    const double den = nodes_v.f64(nd + 16), sden = nodes_v.f64(nd + 24), b = nodes_v.f64(nd + 32), sb = nodes_v.f64(nd + 40),
+                 u0 = nodes_v.f64(nd + 48), u1 = nodes_v.f64(nd + 56), u2 = nodes_v.f64(nd + 64), u3 = nodes_v.f64(nd + 72);
     TopSegment t;
     t.d0 = den + sden * o;  t.d1 = sden * s;
     t.b0 = cY * (b + sb * o);  t.b1 = cY * (sb * s);
@@ -1012,8 +1048,8 @@ struct LeanResult {
 // caller continues from there in the reference's operation order.
 // TOP: with the top-segment phase (long grids on a uniform altitude grid); the short-grid callers use the
 // variant without it, which needs 24 fewer vector registers around the call.
-template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
-__device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigned hint_lds,
+template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP, bool G>
+__device__ __forceinline__ LeanResult lean_loop_body(typename NodeArg<G>::type nodes_arg, unsigned hint_lds,
                                                      const double2* __restrict__ pairs, int first, int end,
                                                      int last_special, double span, double a0, double kj,
                                                      double cX, double cY2, double well_conditioned) {
@@ -1029,9 +1065,20 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
         (unsigned)uniform((int)(unsigned long long)pairs));
     const int lane = threadIdx.x & 63;
     double a0v = a0;                                   // VGPR copies: v_fma / v_mad take one SGPR operand
-    unsigned nodes_v = (unsigned)uniform((int)nodes_lds);
     unsigned hint_v = (unsigned)uniform((int)hint_lds);
-    asm volatile("" : "+v"(a0v), "+v"(nodes_v), "+v"(hint_v));
+    NodeSpace<G> nodes_v;
+    if constexpr (G) {
+        // a slab of global memory: its address back into scalar registers, then a buffer resource over it
+        const unsigned long long addr = (unsigned long long)nodes_arg;
+        const Node* base = reinterpret_cast<const Node*>(
+            ((unsigned long long)(unsigned)uniform((int)(addr >> 32)) << 32) | (unsigned)uniform((int)addr));
+        nodes_v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<Node*>(base), 0, 0x7fffffff, 0x00020000);
+        asm volatile("" : "+v"(a0v), "+v"(hint_v));
+    } else {
+        unsigned nodes_lds_v = (unsigned)uniform((int)nodes_arg);
+        asm volatile("" : "+v"(a0v), "+v"(nodes_lds_v), "+v"(hint_v));
+        nodes_v.base = nodes_lds_v;
+    }
     // Pair-table loads go through a buffer descriptor: lane offset in a VGPR, grid position in an
     // SGPR, so the loop spends no vector instruction on addresses.  A prefetch may reach up to 127 entries
     // past `end`: the table is padded by PRHF_PAIR_PAD entries (launch_grid_pairs), and what is read there
@@ -1079,8 +1126,7 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
             if (j < 0 || n_seg != sidx || sidx >= max_seg) break;
             double m_star;
             if (HINT) {
-                typedef __attribute__((address_space(3))) const double* LdsDouble;
-                const double off_j = *(LdsDouble)(uintptr_t)(nodes_v + __umul24((unsigned)j, (unsigned)sizeof(Node)) + 8u);
+                const double off_j = nodes_v.f64(__umul24((unsigned)j, (unsigned)sizeof(Node)) + 8u);
                 m_star = uniform(-off_j / span);
             } else {
                 m_star = uniform((double)j / kj);
@@ -1127,14 +1173,14 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
         for (; first + 128 <= stop; first += 128) {
             const double2 g1 = grid_at(first + 64);
             if (!CHECK) {
-                accm = lean_step<MODE, false, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+                accm = lean_step<MODE, false, POLY, HINT, G>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
                 g0 = grid_at(first + 128);
-                accm = lean_step<MODE, false, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+                accm = lean_step<MODE, false, POLY, HINT, G>(g1, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
             } else {
                 unsigned long long viol2 = 0;
-                const double a1 = lean_step<MODE, true, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+                const double a1 = lean_step<MODE, true, POLY, HINT, G>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
                 const double2 g2 = grid_at(first + 128);
-                const double a2 = lean_step<MODE, true, POLY, HINT>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, cur);
+                const double a2 = lean_step<MODE, true, POLY, HINT, G>(g1, span, a0v, kj, cX, hcY2, a1, wc, viol2, nodes_v, cur);
                 if (viol) {                            // keep the points in front of the first one that fails
                     const int L = __ffsll((long long)viol) - 1;
                     if (lane < L) accm = a1;
@@ -1153,7 +1199,7 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
             }
         }
         if (first + 64 <= stop) {                      // odd whole wave-iteration left over
-            const double a1 = lean_step<MODE, CHECK, POLY, HINT>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+            const double a1 = lean_step<MODE, CHECK, POLY, HINT, G>(g0, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
             if (!(CHECK && viol)) {
                 accm = a1;
                 first += 64;
@@ -1238,7 +1284,7 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
             // an idle lane re-evaluates a live point with weight 0: grid point 0 - or, under the cursor (whose lanes may
             // only move up), this iteration's first point, which lies above everything the lane has seen
             if (!live) g = make_double2(HINT ? uniform(g0.x) : 0.0, 0.0);
-            a1 = lean_step<MODE, CHECK, POLY, HINT>(g, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
+            a1 = lean_step<MODE, CHECK, POLY, HINT, G>(g, span, a0v, kj, cX, hcY2, accm, wc, viol, nodes_v, cur);
         }
         if (!(CHECK && viol)) {
             accm = a1;
@@ -1256,20 +1302,20 @@ __device__ __forceinline__ LeanResult lean_loop_body(unsigned nodes_lds, unsigne
     return r;
 }
 
-template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP>
-__device__ __attribute__((noinline)) LeanResult lean_loop(unsigned nodes_lds, unsigned hint_lds,
+template <int MODE, bool CHECK, int POLY, bool HINT, bool TOP, bool G>
+__device__ __attribute__((noinline)) LeanResult lean_loop(typename NodeArg<G>::type nodes_arg, unsigned hint_lds,
                                                           const double2* __restrict__ pairs, int first, int end,
                                                           int last_special, double span, double a0, double kj,
                                                           double cX, double cY2, double well_conditioned) {
-    return lean_loop_body<MODE, CHECK, POLY, HINT, TOP>(nodes_lds, hint_lds, pairs, first, end, last_special, span, a0, kj,
-                                                         cX, cY2, well_conditioned);
+    return lean_loop_body<MODE, CHECK, POLY, HINT, TOP, G>(nodes_arg, hint_lds, pairs, first, end, last_special, span, a0,
+                                                            kj, cX, cY2, well_conditioned);
 }
 
 // ---------------------------------------------------------------------------------------
 // S7-S11 for grid points [i0, i1) of one pair; returns this wave's partial sum (all lanes).
 // The multiplier loads of iteration n+1 are issued before the arithmetic of iteration n.
 // ---------------------------------------------------------------------------------------
-template <int MODE, int TIER, bool UNMAG>
+template <int MODE, int TIER, bool UNMAG, bool G>
 __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes,
                                                   const unsigned short* __restrict__ hint,
                                                   const BlockInfo& info, const double* __restrict__ mult,
@@ -1308,11 +1354,20 @@ __device__ __forceinline__ double integrate_chunk(const Node* __restrict__ nodes
             // see lean_loop
             typedef __attribute__((address_space(3))) const Node* LdsNodes;
             typedef __attribute__((address_space(3))) const unsigned short* LdsU16;
-            const unsigned nodes_lds = (unsigned)(uintptr_t)(LdsNodes)nodes;
+            typename NodeArg<G>::type nodes_lds;       // (G: the slab's address itself)
+            if constexpr (G) {
+                nodes_lds = nodes;
+            } else {
+                // (opaque to interprocedural constant propagation: told that every caller passes the dynamic-LDS base,
+                //  the compiler drops the argument and has the loop function look the base up in a table in memory)
+                unsigned at = (unsigned)(uintptr_t)(LdsNodes)nodes;
+                asm volatile("" : "+v"(at));
+                nodes_lds = at;
+            }
             const unsigned hint_lds = (unsigned)(uintptr_t)(LdsU16)hint;
             const int poly = info.poly_angle == 4 ? 4 : 4 - info.poly_angle;    // degree: 3 cubic, 2 quadratic, 1 linear; 4: rotation form
             LeanResult r;
-#define PRHF_LEAN(P, H, T) lean_loop<MODE, TIER == 0, P, H, T>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
+#define PRHF_LEAN(P, H, T) lean_loop<MODE, TIER == 0, P, H, T, G>(nodes_lds, hint_lds, pairs, first, lean_end, last_special, \
                                                                  span, a0, kj, cX, cY2, well_conditioned)
 #define PRHF_LEAN_POLY(H, T) (poly == 1 ? PRHF_LEAN(1, H, T) : (poly == 2 ? PRHF_LEAN(2, H, T) : PRHF_LEAN(3, H, T)))
             if (poly == 4) r = by_hint ? PRHF_LEAN(4, true, false) : PRHF_LEAN(4, false, false);
@@ -1673,7 +1728,7 @@ __device__ __forceinline__ bool collapsed_grid_sum(const Node* nodes, const Bloc
     return true;
 }
 
-template <int MODE, int TIER, int THREADS>
+template <int MODE, int TIER, int THREADS, bool G>
 __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, const Node* nodes,
                                           const double* pf2, const double* gb, const unsigned short* hint,
                                           const unsigned short* cand, const BlockInfo& info, long long prof_local,
@@ -1742,10 +1797,10 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
                 const int i0 = c * sg.chunk_len;
                 const int i1 = min(sg.n_points, i0 + sg.chunk_len);
                 if (info.unmag)
-                    result = integrate_chunk<MODE, TIER, true>(nodes, hint, info, mult, pairs, sg.n_points, i0, i1,
+                    result = integrate_chunk<MODE, TIER, true, G>(nodes, hint, info, mult, pairs, sg.n_points, i0, i1,
                                                                pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
                 else
-                    result = integrate_chunk<MODE, TIER, false>(nodes, hint, info, mult, pairs, sg.n_points, i0,
+                    result = integrate_chunk<MODE, TIER, false, G>(nodes, hint, info, mult, pairs, sg.n_points, i0,
                                                                 i1, pf.f_hz, pf.f2, pf.cX, pf.cY2, h, lane, wc);
             } else if (info.K == 1) {
                 result = (c == C - 1) ? one_level_term<MODE, TIER>(nodes, info, pf, sg.well_conditioned) : 0.0;
@@ -1780,7 +1835,7 @@ __device__ __forceinline__ void run_items(const KArgs& a, const SegDev& sg, cons
 }  // namespace
 
 // Returns the wall clock at the end of staging in -DPRHF_TRACE builds (0 otherwise).
-template <int TIER, int THREADS>
+template <int TIER, int THREADS, bool G>
 __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const SegDev& sg, Node* nodes, double* pf2, double* gb,
                                           unsigned short* hint, unsigned short* cand, int* cand_count, double* red,
                                           long long prof_local, int block_in_prof, int blocks_per_prof,
@@ -1818,10 +1873,10 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
         if (sg.chunks > 1 && sg.slots == 0) a.altmin[sg.altmin_off + prof_local] = kept_scalars<THREADS>(red)[kKeepAltMin];
     }
     if (sg.mode == PRHF_KMODE_O)
-        run_items<PRHF_KMODE_O, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
+        run_items<PRHF_KMODE_O, TIER, THREADS, G>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     else
-        run_items<PRHF_KMODE_X, TIER, THREADS>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
+        run_items<PRHF_KMODE_X, TIER, THREADS, G>(a, sg, nodes, pf2, gb, hint, cand, info, prof_local, block_in_prof,
                                                blocks_per_prof, item_next, red);
     return t_staged;
 }
@@ -1914,9 +1969,9 @@ __device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
         }
 
         const unsigned long long t_staged = (TIER_SEL == 0 || (TIER_SEL == 2 && sg.tier == 0))
-            ? run_block<0, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+            ? run_block<0, THREADS, TALL>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
                                     &item_next)
-            : run_block<1, THREADS>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
+            : run_block<1, THREADS, TALL>(a, sg, nodes, pf2, gb, hint, cand, cand_count, red, prof_local, block_in_prof, bpp,
                                     &item_next);
         (void)t_staged;
 #ifdef PRHF_TRACE

@@ -30,3 +30,11 @@ for mode, n in (("X", 20000), ("X", 2000), ("O", 200)):
     run("1401 levels, global-memory slabs (trim_lds = 0)", 1401, mode, n)
     library.set_option("trim_lds", 1)
     run("6200 levels (0.1 km): global-memory slabs", 6200, mode, n)
+# ... and the generic loop on the same slabs (what tall profiles took up to round 4): option tall_lean = 0
+library.set_option("tall_lean", 0)
+for mode, n in (("X", 20000), ("X", 2000), ("O", 200)):
+    library.set_option("trim_lds", 0)
+    run("1401 levels, global-memory slabs, generic loop (tall_lean = 0)", 1401, mode, n)
+    library.set_option("trim_lds", 1)
+    run("6200 levels (0.1 km): global-memory slabs, generic loop (tall_lean = 0)", 6200, mode, n)
+library.set_option("tall_lean", 1)
