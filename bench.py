@@ -22,6 +22,9 @@ on 127.0.0.1) when it is not already running under a launcher; under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it is given.
 Rank 0 prints ONE JSON line.  `value` counts every submitted (profile, frequency) pair; the
 reflecting fraction is reported beside it.  Inputs are resident in HBM before the timed region.
+`roofline.traffic` (HBM bytes per launch) of the default single-GPU workload is measured by two short child
+runs of this script under `rocprofv3 --pmc` before the timed run (measure_traffic_live; --no-traffic: replayed
+from profiles/hbm_traffic.json); `roofline.traffic_source` says which.
 """
 
 from __future__ import annotations
@@ -254,6 +257,48 @@ def self_launch(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+def measure_traffic_live(kernel_substring="vfo_kernel<1"):
+    """HBM bytes per launch of the default workload's kernel, measured NOW: two short child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE - counters in their own passes, never beside a trace), started
+    before this process touches the GPU.  Units and the gfx950 correction as MI355X_MICROARCH.md prescribes (both
+    counters in KiB; FETCH_SIZE tallies a wide coalesced read at half its bytes: doubled).  Returns a dict, or None
+    when anything at all goes wrong - the caller then falls back to the committed profile's figure and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not os.path.exists("/dev/kfd") or shutil.which("rocprofv3") is None:
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="prhf_traffic_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-single-profile",
+                   "--no-legs", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp", PRHF_BENCH_CHILD="1")
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if done.returncode != 0:
+                return None
+            values = []
+            for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == ctr and kernel_substring in r.get("Kernel_Name", ""):
+                            values.append(float(r["Counter_Value"]))
+            if not values:
+                return None
+            out[ctr] = sum(values) / len(values)
+            out[ctr + "_dispatches"] = len(values)
+        out["hbm_bytes_per_launch"] = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+        return out
+    except Exception:                          # noqa: BLE001 - a profiler that is missing, refused or slow must not sink the bench line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,6 +319,9 @@ def main():
                     help="a context option of the library (prhf_ctx_set_option), e.g. shortx_kernel=0: A/B measurements")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the extra driver-timed legs (config3, config5_shard, config4_full) of the default run")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure the HBM traffic of the default workload live (two short child runs under rocprofv3 "
+                         "--pmc before the timed run): roofline.traffic is then replayed from profiles/hbm_traffic.json")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: initialise the process group anyway and push the result rows through the real "
                          "all_gather_into_tensor (RCCL with one rank) - the N > 1 code path on one GPU")
@@ -281,6 +329,15 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
+
+    # roofline.traffic of the default single-GPU workload: measured in this run, by child processes, before this process
+    # initialises the GPU (the PMC passes cannot share a process with the timed run)
+    live_traffic = None
+    default_workload = (args.workload == "config4" and args.profiles is None and args.freqs is None and
+                        args.n_points is None and args.mode is None and args.math is None and not args.option)
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and default_workload and not args.no_traffic and
+            not args.force_collective and not os.environ.get("PRHF_BENCH_CHILD")):
+        live_traffic = measure_traffic_live()
 
     # stdout carries the one JSON line and nothing else: whatever the libraries below print on file descriptor 1
     # (Gloo announces its connections there) goes to stderr instead
@@ -452,6 +509,14 @@ def main():
                 traffic = rec[key].get("hbm_bytes_per_launch")
                 traffic_src = (f"NOT measured in this run: replayed from profiles/hbm_traffic.json[{key}] "
                                f"(rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of this workload, {rec[key].get('source')})")
+        if live_traffic is not None:
+            replayed = traffic
+            traffic = live_traffic["hbm_bytes_per_launch"]
+            traffic_src = (f"measured in this run: two child runs of this script (2 steps each) under rocprofv3 --pmc before the "
+                           f"timed run - FETCH_SIZE {live_traffic['FETCH_SIZE']:.1f} KiB x 2 (gfx950: a wide coalesced read is "
+                           f"tallied at half its bytes) + WRITE_SIZE {live_traffic['WRITE_SIZE']:.1f} KiB, mean of "
+                           f"{live_traffic['FETCH_SIZE_dispatches']} dispatches of the fused kernel" +
+                           (f"; the committed profile (profiles/hbm_traffic.json) has {replayed:.0f} B" if replayed else ""))
         default_tier = _native.MATH_FAST if (mode == "X" and math is None) else (math if math is not None
                                                                                   else _native.MATH_FAITHFUL)
         result = {
