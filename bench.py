@@ -278,8 +278,18 @@ def measure_traffic_live(kernel_substring="vfo_kernel<1"):
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-single-profile",
                    "--no-legs", "--no-traffic"]
             env = dict(os.environ, TMPDIR="/tmp", PRHF_BENCH_CHILD="1")
-            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            if done.returncode != 0:
+            # (a process group of its own: a pass that overruns is ended with everything it started, so that nothing of
+            #  it is still on the GPU when the timed run begins)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                code = child.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                return None
+            if code != 0:
                 return None
             values = []
             for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
