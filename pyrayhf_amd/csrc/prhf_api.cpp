@@ -212,6 +212,7 @@ struct prhf_ctx {
     DevBuf leftover;  // short-grid launches: the profiles left to the general kernel (count + block indices)
     DevBuf leftover_x;   // ... of the X-mode short-grid launch
     DevBuf leftover_tall;   // compact short-grid launch: the profiles whose bottomside needs the full-size arrays
+    DevBuf leftover_tall_x; // ... of the X-mode short-grid launch
     DevBuf order;           // short-grid launch: its blocks by cost class (short_order_kernel)
     DevBuf tall;         // profiles of more than kMaxAlt levels: one slab of staged levels per resident workgroup
     const double* pairs_src = nullptr;   // PRHF_FLAG_GRID_STABLE: multiplier array the table was built from
@@ -758,6 +759,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
     if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots))
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 6 * sizeof(unsigned), c->stream));         // the launches' block queues
+        HIP_TRY(hipMemsetAsync(c->d_status + 8, 0, sizeof(unsigned), c->stream));         // (... of the X-mode short grids' second launch)
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
     // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
@@ -821,14 +823,43 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         as.leftover = static_cast<unsigned*>(left.p);
         HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
         if (xmode) {
-            const size_t lds = prhf::shortx_lds_bytes(lds_levels, n_freq);
-            const long long short_slots = (long long)c->cu_count * (lds <= lds_half ? 2 : 1);
+            // the compact geometry of the O kernel (four 4-wave workgroups per CU, staged arrays for as many levels as a
+            // quarter of the LDS holds), taken on the same condition; a profile that peaks above them joins the other
+            // input shapes on the general kernel's list (no second short-grid launch here)
+            long long Lx = 0;
+            if (kn.short_compact != 0) {
+                long long L = lds_levels;
+                while (L > 1 && prhf::shortx_lds_bytes(L, n_freq) > lds_quarter) --L;
+                if (2 * L >= lds_levels && L >= 8 && prhf::shortx_lds_bytes(L, n_freq) <= lds_quarter) Lx = L;
+            }
+            const int threads = Lx > 0 ? PRHF_COMPACT_THREADS : PRHF_SHORT_THREADS;
+            const bool second_x = Lx > 0 && Lx < lds_levels;      // some bottomsides may not fit the compact arrays
+            if (Lx > 0) as.lds_levels = Lx;
+            if (second_x) {
+                if ((rcl = ensure(c, c->leftover_tall_x, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
+                as.leftover_tall = static_cast<unsigned*>(c->leftover_tall_x.p);
+                HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
+            }
+            const size_t lds = prhf::shortx_lds_bytes(as.lds_levels, n_freq);
+            const long long short_slots = (long long)c->cu_count * (Lx > 0 ? PRHF_COMPACT_WGS_PER_CU : (lds <= lds_half ? 2 : 1));
             long long grid_short = short_blocks;
             if (short_blocks > short_slots) {
                 as.queue = c->d_status + 4;
                 grid_short = short_slots;
             }
-            HIP_TRY(prhf::launch_vfo_shortx(as, grid_short, lds, short_stream));
+            HIP_TRY(prhf::launch_vfo_shortx(as, grid_short, lds, threads, short_stream));
+            if (second_x) {
+                // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
+                // the device; what these leave - another input shape - joins the general list
+                prhf::KArgs a2 = as;
+                a2.lds_levels = lds_levels;
+                a2.block_list = as.leftover_tall;
+                a2.leftover_tall = nullptr;
+                a2.queue = c->d_status + 8;
+                const size_t lds2 = prhf::shortx_lds_bytes(lds_levels, n_freq);
+                const long long slots2 = (long long)c->cu_count * (lds2 <= lds_half ? 2 : 1);
+                HIP_TRY(prhf::launch_vfo_shortx(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, short_stream));
+            }
         } else {
             const bool compact = compact_levels > 0;
             const bool second = compact && compact_levels < lds_levels;    // some bottomsides may not fit the compact arrays
@@ -1069,11 +1100,11 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = create_events_untimed(c->slab_done, 3)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 8 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 12 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), PRHF_STATUS_WORDS * sizeof(unsigned),
                            hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_status_dev), c->h_status, 0)) != hipSuccess ||
-        (e = hipMemset(c->d_status, 0, 8 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_status, 0, 12 * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocMapped | hipHostMallocCoherent)) !=
             hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_pack_dev), c->h_pack, 0)) != hipSuccess ||
@@ -1115,6 +1146,7 @@ int prhf_ctx_destroy(prhf_ctx* c) {
     if (c->leftover.p) (void)hipFree(c->leftover.p);
     if (c->leftover_x.p) (void)hipFree(c->leftover_x.p);
     if (c->leftover_tall.p) (void)hipFree(c->leftover_tall.p);
+    if (c->leftover_tall_x.p) (void)hipFree(c->leftover_tall_x.p);
     if (c->order.p) (void)hipFree(c->order.p);
     if (c->tall.p) (void)hipFree(c->tall.p);
     for (int g = 0; g < c->n_host_grids; ++g) {

@@ -188,8 +188,8 @@ hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_by
 // the blocks of the short-grid launch `a` sorted into cost classes: order[0 .. CLASSES) counts (zeroed by the caller),
 // then CLASSES lists of a.n_blocks entries
 hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream);
-// the X-mode variant; lds_bytes = shortx_lds_bytes
-hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream);
+// the X-mode variant; lds_bytes = shortx_lds_bytes(a.lds_levels, n_freq); threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
+hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words
 hipError_t launch_mu_mup(const double* X, const double* Y, const double* psi, long long n, int mode, int tier,
                          unsigned long long* absmax_scratch, unsigned long long* absmax_host,

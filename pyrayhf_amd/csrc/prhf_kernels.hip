@@ -2487,10 +2487,16 @@ hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, hipStream_t stream) {
-    constexpr int THREADS = PRHF_SHORT_THREADS;
+hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream) {
     if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((vfo_shortx_kernel<THREADS>), dim3((unsigned)grid_blocks), dim3(THREADS), lds_bytes, stream, a);
+    if (threads == PRHF_COMPACT_THREADS)
+        hipLaunchKernelGGL((vfo_shortx_kernel<PRHF_COMPACT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_COMPACT_THREADS),
+                           lds_bytes, stream, a);
+    else if (threads == PRHF_SHORT_THREADS)
+        hipLaunchKernelGGL((vfo_shortx_kernel<PRHF_SHORT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_SHORT_THREADS),
+                           lds_bytes, stream, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -2514,6 +2520,7 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
                              reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS>),
                              reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_COMPACT_THREADS>),
                              reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_SHORT_THREADS>),
+                             reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_COMPACT_THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);

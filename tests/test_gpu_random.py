@@ -273,7 +273,8 @@ def test_random_tall_columns(seed):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_compact_short_grid_geometry_changes_nothing(seed):
-    """Short O-mode grids run on four 4-wave workgroups per CU whose staged arrays hold part of the column (round 4);
+    """Short grids run on four 4-wave workgroups per CU whose staged arrays hold part of the column (round 4: O mode,
+    vfo_short_kernel; second session: X mode, vfo_shortx_kernel);
     profiles that peak above them take a second launch with full-size arrays, other input shapes the general kernel.
     Random batches - columns of 150 - 1300 levels, layers peaking anywhere in them, valleys, plateaus, a vacuum at the
     bottom, fast-turning field angles, non-uniform altitudes in some - must come out bit for bit as with
@@ -314,6 +315,15 @@ def test_compact_short_grid_geometry_changes_nothing(seed):
             assert np.isfinite(base).any()
             for key, got in outs.items():
                 assert np.array_equal(got, base, equal_nan=True), (seed, n_alt, F, n, key)
+            # the X-mode short-grid kernel has the same two geometries (second session of round 4): a profile that
+            # peaks above the compact arrays takes a second launch of the same kernel with full-size arrays
+            library.set_option("short_queue", 0)
+            xs = []
+            for compact in (0, 1):
+                library.set_option("short_compact", compact)
+                xs.append(library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "X", n))
+            assert np.isfinite(xs[0]).any()
+            assert np.array_equal(xs[0], xs[1], equal_nan=True), (seed, n_alt, F, n, "X")
     finally:
         library.set_option("short_compact", 1)
         library.set_option("short_queue", 0)
