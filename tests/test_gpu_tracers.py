@@ -214,3 +214,46 @@ def test_per_profile_level_table_changes_no_bit(spherical):
                 assert np.array_equal(few[4.0][key], few[1.0][key], equal_nan=True), (mode, key)
     finally:
         library.set_option("snell_table", 4.0)
+
+
+@pytest.mark.parametrize("spherical", [False, True])
+def test_random_rays_against_the_oracle(spherical):
+    """240 random rays (frequency, elevation, profile; both modes) over seeded Chapman profiles against the NumPy
+    restatement of the reference's tracers (oracle/snell_numpy.py, itself held to the reference-run rays of G8 / G9):
+    the same rays turn, and path length, group delay, ground range and every path node agree to the fixtures' 1e-12
+    (flat) / 1e-11 (spherical).  Covers what the fixtures' two profiles do not: the per-profile level table across 16
+    profiles, E-F valleys, oblique and near-vertical rays in one launch."""
+    from oracle import snell_numpy as sn
+    from pyrayhf_amd import synth, tracers
+    alt, den, bmag, bpsi = synth.chapman_profiles(16, 4242)
+    rng = np.random.default_rng(99 + int(spherical))
+    n = 120
+    f = rng.uniform(2e6, 15e6, n)
+    e = np.concatenate([rng.uniform(3.0, 88.0, n - 10), rng.uniform(88.0, 90.0, 10)])
+    idx = rng.integers(0, 16, n)
+    fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+    ofn = sn.trace_spherical if spherical else sn.trace_cartesian
+    rtol = 1e-11 if spherical else 1e-12
+    turned = 0
+    for mode in "OX":
+        got = fn(f, e, alt, den, bmag, bpsi, mode, profile_index=idx, return_paths=True)
+        for k in range(n):
+            with np.errstate(all="ignore"):
+                want = ofn(f[k], e[k], alt, den[idx[k]], bmag[idx[k]], bpsi[idx[k]], mode)
+            traced = np.isfinite(want["group_path_km"])
+            assert np.isfinite(got["group_path_km"][k]) == traced, (mode, k)
+            if not traced:
+                assert got["n_path"][k] == 0
+                continue
+            turned += 1
+            for key in ("group_path_km", "group_delay_sec"):
+                assert abs(got[key][k] - want[key]) <= rtol * abs(want[key]), (mode, k, key, got[key][k], want[key])
+            gr = want["ground_range_km"]
+            assert np.isnan(got["ground_range_km"][k]) == np.isnan(gr)
+            if np.isfinite(gr):
+                assert abs(got["ground_range_km"][k] - gr) <= rtol * abs(gr) + 1e-10
+            m = want["x"].size
+            assert got["n_path"][k] == m
+            np.testing.assert_allclose(got["x"][k, :m], want["x"], rtol=rtol, atol=1e-9)
+            np.testing.assert_allclose(got["z"][k, :m], want["z"], rtol=rtol, atol=1e-11)
+    assert turned > 100
