@@ -8,14 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 
-KMAX = 270
+KMAX = int(os.environ.get("AB_KMAX", "270"))
 
 def child(tag):
     import torch
     from pyrayhf_amd import library, synth, _native
     dev = torch.device("cuda", 0)
     ctx = _native.context(0)
-    alt, den, bmag, bpsi = synth.chapman_profiles(16000, 20260003)
+    alt, den, bmag, bpsi = synth.chapman_profiles(40000, 20260003)
     keep = np.nonzero(np.argmax(den, axis=1) < KMAX)[0][:5000]
     assert keep.size == 5000
     keep = np.concatenate([keep, keep])                      # 10 000 rows: ten resident rounds, as config 3
