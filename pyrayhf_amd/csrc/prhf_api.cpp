@@ -445,7 +445,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     // covered by three others' items (config 3: -10 %).  A quarter of the LDS holds the lists and fewer levels than
     // the column has; a profile whose peak lies above them goes to a second launch with full-size arrays.  Taken when
     // those arrays hold at least half of the column (PyIRI columns peak at 25 - 50 % of their height).
-    const size_t lds_quarter = (160 * 1024) / PRHF_COMPACT_WGS_PER_CU - 512;
+#ifndef PRHF_COMPACT_RESERVE
+#define PRHF_COMPACT_RESERVE 512    // bytes kept back per workgroup for its static LDS (tickets, counters)
+#endif
+    const size_t lds_quarter = (160 * 1024) / PRHF_COMPACT_WGS_PER_CU - PRHF_COMPACT_RESERVE;
     long long compact_levels = 0;
     int compact_queue = 0;
     if (kn.short_compact != 0 && short_queue > 0) {
