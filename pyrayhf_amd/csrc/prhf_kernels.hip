@@ -2161,17 +2161,36 @@ __global__ void mu_mup_kernel(const double* __restrict__ X, const double* __rest
     const bool wide = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(psi) |
                         reinterpret_cast<uintptr_t>(mu_out) | reinterpret_cast<uintptr_t>(mup_out)) & 15) == 0;
     const long long n2 = wide ? n >> 1 : 0;
-    for (long long i = tid; i < n2; i += stride) {
-        typedef double vec2 __attribute__((ext_vector_type(2)));
-        // (plain loads, streaming stores: non-temporal loads measured no better)
-        const vec2 x = reinterpret_cast<const vec2*>(X)[i], y = reinterpret_cast<const vec2*>(Y)[i];
-        const vec2 ps = reinterpret_cast<const vec2*>(psi)[i];
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    auto pair_of = [&](long long i, vec2 x, vec2 y, vec2 ps) {
         double mu0, mup0, mu1, mup1;
         one(x.x, y.x, ps.x, &mu0, &mup0);
         one(x.y, y.y, ps.y, &mu1, &mup1);
         const vec2 m = {mu0, mu1}, mp = {mup0, mup1};
         __builtin_nontemporal_store(m, reinterpret_cast<vec2*>(mu_out) + i);
         __builtin_nontemporal_store(mp, reinterpret_cast<vec2*>(mup_out) + i);
+    };
+    // (plain loads, streaming stores: non-temporal loads measured no better; the loads of two trips are issued
+    //  together - 96 bytes per lane in flight - before the arithmetic of the first)
+    // (every workgroup streams through a contiguous piece of the arrays - not a grid-wide stride, which has 4096
+    //  workgroups x 5 arrays open as many DRAM pages at once)
+    const long long piece = (n2 + gridDim.x - 1) / gridDim.x;
+    const long long p_end = (blockIdx.x + 1) * piece < n2 ? (blockIdx.x + 1) * piece : n2;
+    const long long step = blockDim.x;
+    long long i = blockIdx.x * piece + threadIdx.x;
+    for (; i + step < p_end; i += 2 * step) {
+        const long long k = i + step;
+        const vec2 x0 = reinterpret_cast<const vec2*>(X)[i], y0 = reinterpret_cast<const vec2*>(Y)[i];
+        const vec2 p0 = reinterpret_cast<const vec2*>(psi)[i];
+        const vec2 x1 = reinterpret_cast<const vec2*>(X)[k], y1 = reinterpret_cast<const vec2*>(Y)[k];
+        const vec2 p1 = reinterpret_cast<const vec2*>(psi)[k];
+        pair_of(i, x0, y0, p0);
+        pair_of(k, x1, y1, p1);
+    }
+    for (; i < p_end; i += step) {
+        const vec2 x = reinterpret_cast<const vec2*>(X)[i], y = reinterpret_cast<const vec2*>(Y)[i];
+        const vec2 ps = reinterpret_cast<const vec2*>(psi)[i];
+        pair_of(i, x, y, ps);
     }
     for (long long i = 2 * n2 + tid; i < n; i += stride) {
         double mu, mup;
