@@ -17,7 +17,8 @@ from . import _native
 from .library import _as_rows, constants
 
 __all__ = ["trace_ray_cartesian_snells", "trace_rays_cartesian_snells", "trace_ray_spherical_snells",
-           "trace_rays_spherical_snells", "trace_fan_cartesian_snells", "trace_fan_spherical_snells"]
+           "trace_rays_spherical_snells", "trace_fan_cartesian_snells", "trace_fan_spherical_snells",
+           "tan_from_mu_scalar", "find_turning_point"]
 
 _KEYS = ("group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km", "x_turn_km",
          "z_turn_km", "n_path")
@@ -174,3 +175,27 @@ def trace_ray_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mod
                                     dz_target_km=dz_target_km, apex_boost=apex_boost, max_substeps=max_substeps,
                                     R_E=R_E, return_paths=True, device=device)
     return _single(r, apex_keys=False)
+
+
+def tan_from_mu_scalar(mu_val, p):
+    """Tangent of the ray's angle to the vertical where the phase index is ``mu_val`` and the Snell invariant ``p``
+    (reference ``library.py:1034-1062``): ``p / sqrt(max(mu_val**2 - p**2, 1e-10))``.  A host helper beside the
+    tracers, which apply the same rule inside the kernel; array arguments broadcast."""
+    mu_val = np.asarray(mu_val, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    out = p / np.sqrt(np.maximum(mu_val * mu_val - p * p, 1e-10))
+    return float(out) if out.ndim == 0 else out
+
+
+def find_turning_point(z, mu, p):
+    """Altitude at which ``mu`` falls through the Snell invariant ``p``: the first pair of neighbouring nodes with
+    ``mu[i] >= p >= mu[i + 1]``, linear in between, NaN when there is none (reference ``library.py:1065-1093``)."""
+    z = np.asarray(z, dtype=np.float64).ravel()
+    mu = np.asarray(mu, dtype=np.float64).ravel()
+    hit = np.nonzero((mu[:-1] >= p) & (mu[1:] <= p))[0]
+    if hit.size == 0:
+        return float("nan")
+    i = int(hit[0])
+    if mu[i] == mu[i + 1]:
+        return float(z[i])
+    return float(z[i] + ((mu[i] - p) / (mu[i] - mu[i + 1])) * (z[i + 1] - z[i]))

@@ -50,3 +50,21 @@ def test_batch_npz_round_trip(tmp_path):
     assert int(back["meta"]["seed"]) == 20260001
     with pytest.raises(ValueError):
         pio.save_batch_npz(path, g["alt"][:-1], g["den"][:5], g["bmag"][:5], g["bpsi"][:5])
+
+
+def test_tracer_helpers_like_the_reference():
+    """tan_from_mu_scalar and find_turning_point (reference library.py:1034-1093) - the checks of the reference's
+    test_core.py:613-635 plus the bracket rules of its loop."""
+    from pyrayhf_amd.tracers import find_turning_point, tan_from_mu_scalar
+    np.testing.assert_allclose(tan_from_mu_scalar(2.0, 1.0), 1.0 / np.sqrt(3.0), rtol=1e-12)
+    near = tan_from_mu_scalar(1.0000001, 1.0)
+    assert np.isfinite(near) and near > 0.0
+    assert tan_from_mu_scalar(1.0, 1.0) == 1.0 / np.sqrt(1e-10)          # the 1e-10 floor under the root
+    small = tan_from_mu_scalar(1e-6, 1e-7)
+    assert np.isfinite(small) and small >= 0.0
+    assert tan_from_mu_scalar(np.array([2.0, 3.0]), 1.0).shape == (2,)
+    z = np.array([100.0, 110.0, 120.0, 130.0])
+    assert find_turning_point(z, np.array([1.0, 0.8, 0.4, 0.2]), 0.6) == 115.0
+    assert find_turning_point(z, np.array([1.0, 0.6, 0.6, 0.2]), 0.6) == 100.0 + (0.4 / 0.4) * 10.0   # first bracket
+    assert find_turning_point(z, np.array([0.6, 0.6, 0.4, 0.2]), 0.6) == 100.0                       # equal ends: the lower node
+    assert np.isnan(find_turning_point(z, np.array([1.0, 0.9, 0.8, 0.7]), 0.6))
