@@ -23,7 +23,71 @@ from . import _native
 from .library import _mode_code, _multiplier, _as_rows, _is_torch, _device_grid, _grid_flag, MATH_AUTO
 
 __all__ = ["residual_VH_batch", "brute_force_fit", "peak_density_from_trace", "brute_grid", "minimize_parameters",
-           "resolve_method", "BoundedPair"]
+           "resolve_method", "BoundedPair", "pyiri_edp_builder", "model_VH", "residual_VH"]
+
+
+def pyiri_edp_builder(F2, F1, E, alt, bottom_type='B_bot'):
+    """The electron density profile ``(N_alt,)`` the reference's ``model_VH`` builds with PyIRI (library.py:557-586):
+    the F1 layer re-derived from the F2 parameters, then the one-level reconstruction (``'B_bot'``) or the continuous
+    IRI builder (``'B0_B1'``); the single time / location of the layer dictionaries is picked out (``EDP[0, :, 0]``).
+    The default ``edp_builder`` of ``model_VH`` / ``residual_VH`` / ``minimize_parameters``; needs PyIRI, which neither
+    the reference nor this package vendors (ImportError otherwise).  ``F1`` is updated in place, as in the reference."""
+    try:
+        import PyIRI
+        import PyIRI.edp_update
+        import PyIRI.sh_library
+    except ImportError as exc:          # pragma: no cover - PyIRI is absent from the build and test images
+        raise ImportError("PyIRI is not installed: pass edp_builder=callable(F2, F1, E, alt, bottom_type) -> EDP (N_alt,)") from exc
+    if bottom_type == 'B_bot':
+        derived = PyIRI.edp_update.derive_dependent_F1_parameters(F1['P'], F2['Nm'], F2['hm'], F2['B_bot'], E['hm'])
+        rebuild = PyIRI.edp_update.reconstruct_density_from_parameters_1level
+    elif bottom_type == 'B0_B1':
+        derived = PyIRI.sh_library.derive_dependent_F1_parameters(F1['P'], F2['Nm'], F2['hm'], F2['B0'], F2['B1'], E['hm'])
+        rebuild = PyIRI.sh_library.EDP_builder_continuous
+    else:
+        raise ValueError("bottom_type must be 'B_bot' or 'B0_B1'")
+    F1['Nm'], F1['fo'], F1['hm'], F1['B_bot'] = derived
+    return np.asarray(rebuild(F2, F1, E, alt))[0, :, 0]
+
+
+def model_VH(F2, F1, E, f_in, alt, b_mag, b_psi, mode='O', n_points=200, bottom_type='B_bot', *, edp_builder=None,
+             device=None, math=None):
+    """Modeled virtual-height trace and the electron density profile behind it: the reference's ``model_VH``
+    (library.py:512-592), same positional arguments and ``(vh, EDP)`` result; the profile comes from ``edp_builder``
+    (default: ``pyiri_edp_builder``, the reference's own PyIRI calls), the trace from the GPU operator."""
+    from .library import vertical_forward_operator
+    build = pyiri_edp_builder if edp_builder is None else edp_builder
+    edp = np.asarray(build(F2, F1, E, alt, bottom_type), dtype=np.float64).ravel()
+    return vertical_forward_operator(f_in, edp, b_mag, b_psi, alt, mode, n_points, device=device, math=math), edp
+
+
+def residual_VH(params, F2_init, F1_init, E_init, f_in, vh_obs, alt, b_mag, b_psi, mode='O', n_points=200,
+                bottom_type='B_bot', *, edp_builder=None, device=None, math=None):
+    """``vh_obs - vh_model`` for one set of layer parameters: the reference's ``residual_VH`` (library.py:595-669).
+    ``params`` maps ``'NmF2'``, ``'hmF2'`` and ``'B_bot'`` (or ``'B0'``, ``'B1'``) to numbers or to objects with a
+    ``.value`` (lmfit.Parameters); the layer dictionaries are copied, not mutated; modeled NaNs are replaced by
+    ``max(nanmean|vh_model|, 100)`` as in the reference.  One candidate per call - a search evaluates its candidates
+    together through ``residual_VH_batch``."""
+    from copy import deepcopy
+
+    def number(name):
+        v = params[name]
+        return float(getattr(v, "value", v))
+    F2, F1, E = deepcopy(F2_init), deepcopy(F1_init), deepcopy(E_init)
+    F2['Nm'] = np.full_like(F2_init['Nm'], number('NmF2'))
+    F2['hm'] = np.full_like(F2_init['Nm'], number('hmF2'))
+    if bottom_type == 'B_bot':
+        F2['B_bot'] = np.full_like(F2_init['Nm'], number('B_bot'))
+    elif bottom_type == 'B0_B1':
+        F2['B0'] = np.full_like(F2_init['Nm'], number('B0'))
+        F2['B1'] = np.full_like(F2_init['Nm'], number('B1'))
+    else:
+        raise ValueError("bottom_type must be 'B_bot' or 'B0_B1'")
+    build = pyiri_edp_builder if edp_builder is None else edp_builder
+    edp = np.asarray(build(F2, F1, E, alt, bottom_type), dtype=np.float64).ravel()
+    residual = residual_VH_batch(np.atleast_1d(f_in), np.atleast_1d(vh_obs), edp[None, :], b_mag, b_psi, alt, mode, n_points,
+                                 device=device, math=math, return_cost=False)
+    return residual.ravel()
 
 
 def _sorted_finite(freq, vh_obs):
@@ -308,15 +372,16 @@ def _local_search(residuals, pair, family, scipy_name):
 
 
 def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='brute', percent_sigma=20., step=1.,
-                        mode='O', n_points=200, bottom_type='B_bot', *, edp_builder, device=None, math=None):
+                        mode='O', n_points=200, bottom_type='B_bot', *, edp_builder=None, device=None, math=None):
     """Fit hmF2 and B_bot (or B0) of the F2 layer to an observed trace: the reference's ``minimize_parameters``
     (library.py:672-825) with its brute-force search as ONE batched launch.
 
     Positional arguments, defaults and the returned triple ``(vh_result, EDP_result, F2_fit)`` are the
     reference's.  What the reference gets from PyIRI inside ``model_VH`` (library.py:557-586) comes from the
-    caller here, because PyIRI is not vendored: ``edp_builder(F2, F1, E, alt, bottom_type)`` must return the
-    electron density profile ``(N_alt,)`` [m^-3] for the layer dictionaries it is given - with PyIRI installed,
-    a wrapper around ``reconstruct_density_from_parameters_1level`` / ``EDP_builder_continuous``.
+    ``edp_builder(F2, F1, E, alt, bottom_type)``, which returns the electron density profile ``(N_alt,)`` [m^-3] of
+    the layer dictionaries it is given: by default ``pyiri_edp_builder`` - the reference's own PyIRI calls, so that
+    with PyIRI installed the positional call of the reference works unchanged; any other builder (PyIRI is not
+    vendored, and absent from the build image) as a keyword.
 
     As in the reference: observations are filtered to finite values and sorted (:741-745); NmF2 is fixed from
     the highest observed frequency (+0.01 %, :760-778); hmF2 and B_bot (``bottom_type='B_bot'``) or B0
@@ -343,6 +408,8 @@ def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='br
     if bottom_type not in ('B_bot', 'B0_B1'):
         raise ValueError("bottom_type must be 'B_bot' or 'B0_B1'")
     family, scipy_name = resolve_method(method)
+    if edp_builder is None:
+        edp_builder = pyiri_edp_builder
     f_in0 = np.asarray(f_in0, dtype=np.float64)
     vh_obs0 = np.asarray(vh_obs0, dtype=np.float64)
     alt = np.asarray(alt, dtype=np.float64)

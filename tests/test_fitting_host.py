@@ -73,3 +73,37 @@ def test_a_nan_residual_raises_as_lmfit_does_by_default():
     for family, name in (("leastsq", None), ("least_squares", None), ("scalar", "Powell")):
         with pytest.raises(ValueError, match="NaN values detected"):
             fitting._local_search(residuals, pair, family, name)
+
+
+def test_the_default_builder_is_pyiri_and_says_so_when_it_is_absent():
+    """model_VH / residual_VH / minimize_parameters keep the reference's positional signatures; what the reference
+    builds with PyIRI (library.py:557-586) comes from pyiri_edp_builder by default - PyIRI is absent here, so the call
+    must fail with an ImportError that names the keyword to pass instead (before anything touches the GPU)."""
+    import inspect
+    ref_args = ["F2", "F1", "E", "f_in0", "vh_obs0", "alt", "b_mag", "b_psi", "method", "percent_sigma", "step", "mode",
+                "n_points", "bottom_type"]
+    sig = inspect.signature(fitting.minimize_parameters)
+    assert [p for p, v in sig.parameters.items() if v.kind is v.POSITIONAL_OR_KEYWORD] == ref_args      # library.py:672-674
+    assert [p for p, v in inspect.signature(fitting.model_VH).parameters.items() if v.kind is v.POSITIONAL_OR_KEYWORD] == \
+        ["F2", "F1", "E", "f_in", "alt", "b_mag", "b_psi", "mode", "n_points", "bottom_type"]           # library.py:512-513
+    assert [p for p, v in inspect.signature(fitting.residual_VH).parameters.items() if v.kind is v.POSITIONAL_OR_KEYWORD] == \
+        ["params", "F2_init", "F1_init", "E_init", "f_in", "vh_obs", "alt", "b_mag", "b_psi", "mode", "n_points",
+         "bottom_type"]                                                                                  # library.py:595-596
+    try:
+        import PyIRI  # noqa: F401
+        pytest.skip("PyIRI is installed here")
+    except ImportError:
+        pass
+    one = lambda v: np.array([[[v]]])                                           # noqa: E731
+    F2 = {"Nm": one(1e12), "hm": one(300.0), "B_bot": one(40.0)}
+    F1, E = {"P": one(0.5)}, {"hm": one(110.0)}
+    alt = np.arange(80.0, 500.0)
+    f = np.arange(2.0, 8.0, 0.5)
+    with pytest.raises(ImportError, match="edp_builder"):
+        fitting.model_VH(F2, F1, E, f, alt, np.full(alt.size, 4e-5), np.full(alt.size, 30.0))
+    with pytest.raises(ImportError, match="edp_builder"):
+        fitting.residual_VH({"NmF2": 1e12, "hmF2": 300.0, "B_bot": 40.0}, F2, F1, E, f, np.full(f.size, 250.0), alt,
+                            np.full(alt.size, 4e-5), np.full(alt.size, 30.0))
+    with pytest.raises(ImportError, match="edp_builder"):
+        fitting.minimize_parameters(F2, F1, E, f, np.full(f.size, 250.0), alt, np.full(alt.size, 4e-5),
+                                    np.full(alt.size, 30.0))

@@ -293,3 +293,35 @@ def test_residual_batch_on_gpu_resident_candidates():
                                     bpsi[0], alt, "O", 200, return_vh=True)
     for a, b in zip(got, want):
         assert a.is_cuda and np.array_equal(a.cpu().numpy(), b, equal_nan=True)
+
+
+def test_model_VH_and_residual_VH_keep_the_reference_call():
+    """model_VH (library.py:512-592) and residual_VH (:595-669) with the reference's positional arguments; the profile
+    builder passed as a keyword (PyIRI, their default, is absent here).  residual_VH is the row residual_VH_batch
+    gives for the same candidate - the rows fixture G11 pins to the reference's own residual_VH - bit for bit, with
+    plain numbers or lmfit-style objects as parameters, and the layer dictionaries are left as they were."""
+    from pyrayhf_amd import fitting, library
+    alt = np.arange(80.0, 500.0, 1.0)
+    b_mag = 4.6e-5 * ((6371.0 + 80.0) / (6371.0 + alt)) ** 3
+    b_psi = 35.0 + 0.002 * (alt - alt[0])
+    f_in = np.arange(1.5, 12.0, 0.25)
+    F2, F1, E = _layer_dicts(6.0e11, 300.5, 46.0)
+    vh, edp = fitting.model_VH(F2, F1, E, f_in, alt, b_mag, b_psi, 'X', 200, 'B_bot', edp_builder=_chapman_builder)
+    assert np.array_equal(edp, _chapman_builder(F2, F1, E, alt, 'B_bot'))
+    assert np.array_equal(vh, library.vertical_forward_operator(f_in, edp, b_mag, b_psi, alt, 'X', 200), equal_nan=True)
+    assert np.isnan(vh).any() and np.isfinite(vh).any()
+    obs = np.where(np.isfinite(vh), vh + 1.0, 260.0)
+
+    class P:                                   # what lmfit.Parameters hands over: objects with a .value
+        def __init__(self, v):
+            self.value = v
+    for params in ({"NmF2": 5.0e11, "hmF2": 290.0, "B_bot": 40.0}, {"NmF2": P(5.0e11), "hmF2": P(290.0), "B_bot": P(40.0)}):
+        res = fitting.residual_VH(params, F2, F1, E, f_in, obs, alt, b_mag, b_psi, 'X', 200, 'B_bot',
+                                  edp_builder=_chapman_builder)
+        cand = _chapman_builder(_layer_dicts(5.0e11, 290.0, 40.0)[0], F1, E, alt, 'B_bot')
+        want = fitting.residual_VH_batch(f_in, obs, cand[None, :], b_mag, b_psi, alt, 'X', 200, return_cost=False)[0]
+        assert res.shape == f_in.shape and np.array_equal(res, want)
+        model = library.vertical_forward_operator(f_in, cand, b_mag, b_psi, alt, 'X', 200)
+        filled = np.isnan(model)
+        assert filled.any() and np.all(res[filled] == obs[filled] - max(np.nanmean(np.abs(model)), 100.0))   # :664-665
+    assert float(F2['hm'].squeeze()) == 300.5 and float(F2['Nm'].squeeze()) == 6.0e11
