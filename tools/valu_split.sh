@@ -11,7 +11,7 @@ cd /tmp
 i=0
 while read -r ARGS; do
   i=$((i+1))
-  B="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-profile --no-legs $ARGS"
+  B="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-profile --no-legs --no-traffic $ARGS"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/w$i/trace" -- $B > "$OUT/w$i.json" 2> "$OUT/w$i.trace.log"
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/w$i/pmc" -- $B > /dev/null 2> "$OUT/w$i.pmc.log"
   echo "$ARGS" > "$OUT/w$i.args"
