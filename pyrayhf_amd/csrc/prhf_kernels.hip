@@ -1133,6 +1133,30 @@ __device__ __forceinline__ LeanResult lean_loop_body(typename NodeArg<G>::type n
             }
             int lo = first, hi = search_hi;            // the answer lies in [lo, hi)
             bool found = true;
+            // A guess in closed form first: on the reference's stretched grid (library.py:314-320; the only one the Python
+            // side makes) m_i = 1 - (e^(10 (1 - u_i)) - 1) / (e^10 - 1), u_i = i / (N - 1), so the first i with
+            // m_i >= m_star is ceil((N - 1) (1 - ln(1 + (1 - m_star)(e^10 - 1)) / 10)) - one v_log_f32, good to 1e-3 of
+            // an index here.  Four table entries around it are loaded at once and the answer is taken only if they
+            // bracket it (m below m_star in the first, at or above it in a later one): any other grid - the C ABI takes
+            // every non-decreasing multiplier - or a guess at the range's edge falls through to the search below, which
+            // costs three dependent loads per segment.  The index is the search's own either way.
+            {
+                const double A = __builtin_fma(1.0 - m_star, 22025.465794806718, 1.0);
+                const double ln_a = (double)__builtin_amdgcn_logf((float)A) * 0.6931471805599453;      // (v_log_f32: log2)
+                const double n1 = (double)(CHECK ? i_last + 1 : i_last);                                // N - 1
+                const int base = uniform((int)__builtin_fma(-ln_a, n1 * 0.1, n1)) - 1;                  // floor(i*) - 1
+                if (base >= lo && base + 3 < hi) {
+                    const u32x4 vg = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsrc, (unsigned)(base + (lane & 3)) * (unsigned)sizeof(double2), 0, 0);
+                    double2 gg;
+                    __builtin_memcpy(&gg, &vg, sizeof gg);
+                    const unsigned hit4 = (unsigned)(__ballot(gg.x >= m_star) & 0xfull);
+                    if (hit4 != 0u && (hit4 & 1u) == 0u) {
+                        lo = base + __ffs((int)hit4) - 1;
+                        hi = lo + 1;
+                    }
+                }
+            }
             while (hi - lo > 1) {
                 const int stride = (hi - lo + 63) >> 6;
                 const int probe = min(lo + (lane + 1) * stride - 1, hi - 1);
