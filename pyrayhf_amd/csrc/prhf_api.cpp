@@ -760,9 +760,12 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         if ((rc = ensure(c, c->tall, (size_t)std::min(blocks, wg_slots) * a.tall_stride)) != PRHF_OK) return rc;
         a.tall = static_cast<unsigned char*>(c->tall.p);
     }
-    if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots))
-        HIP_TRY(hipMemsetAsync(c->d_status, 0, 6 * sizeof(unsigned), c->stream));         // the launches' block queues
-        HIP_TRY(hipMemsetAsync(c->d_status + 8, 0, sizeof(unsigned), c->stream));         // (... of the X-mode short grids' second launch)
+    // the launches' block queues: words 0 - 5, and word 8 for the second launch of the X-mode short grids (words 6 and 7
+    // belong to the tracers and the peak pre-pass).  A launch without a queue - the single profile - enqueues neither.
+    if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots)) {
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, 6 * sizeof(unsigned), c->stream));
+        if (n_shortx > 0) HIP_TRY(hipMemsetAsync(c->d_status + 8, 0, sizeof(unsigned), c->stream));
+    }
     // A list with both kinds of slices: the general launch goes first, on the caller's stream, and takes every
     // workgroup slot; the short-grid launch runs on a second stream and its workgroups move in as the general
     // launch's persistent workgroups leave - its 30 - 100 us blocks fill the end of the launch, which otherwise drains
@@ -827,8 +830,8 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
         if (xmode) {
             // the compact geometry of the O kernel (four 4-wave workgroups per CU, staged arrays for as many levels as a
-            // quarter of the LDS holds), taken on the same condition; a profile that peaks above them joins the other
-            // input shapes on the general kernel's list (no second short-grid launch here)
+            // quarter of the LDS holds), taken on the same condition; a profile that peaks above them goes on a block
+            // list of its own, which a second launch of this kernel with full-size arrays takes (a2 below, queue word 8)
             long long Lx = 0;
             if (kn.short_compact != 0) {
                 long long L = lds_levels;

@@ -1910,9 +1910,11 @@ __device__ __forceinline__ unsigned long long run_block(const KArgs& a, const Se
 // profile - nodes, f_N^2, g_p |B| - then lives in a slab of global memory that belongs to this workgroup
 // (KArgs::tall, one slab per resident workgroup: the launch is persistent whenever it has more blocks than slots),
 // and only the hint table, the reduction scratch and the counters stay in LDS.  Every device function takes the
-// staged arrays as generic pointers; the main loop, which addresses its nodes as LDS words, is switched off by the
-// host for such launches (SegDev::lean = 0, no candidate list), so a tall profile runs through the generic loop:
-// same arithmetic as any other profile that leaves the main loop, about three times slower than the LDS path.
+// staged arrays as generic pointers; the main loop reads its nodes through NodeSpace<G> - LDS words in the LDS
+// kernels, the slab behind a buffer resource here (context option tall_lean = 1, the default: 1.1 - 1.4 x the time of
+// the LDS path on long grids) - and with tall_lean = 0 the host switches it off for such launches (SegDev::lean = 0,
+// no candidate list), so that a tall profile runs through the generic loop like any other profile that leaves the
+// main loop (about three times slower).  Same values either way (fixture G13, tests/test_gpu_random.py).
 template <int TIER_SEL, int THREADS, bool TALL>
 __device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

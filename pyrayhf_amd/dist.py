@@ -33,7 +33,9 @@ def shard_counts(n_items, world_size):
 def _exchange(send, world, group, dst):
     """One collective over equal-sized blocks: every rank's ``send`` stacked as ``(world * rows, width)`` - on every
     rank (``dst`` None: ``all_gather_into_tensor``) or on rank ``dst`` alone (``dist.gather``: each peer's block goes
-    to the root over its own xGMI link and nobody else holds the 205 MB of config 4; the others get None)."""
+    to the root over its own xGMI link and nobody else holds the 205 MB of config 4; the others get None).
+    ``dst`` is a global rank (a member of ``group``), the convention of ``torch.distributed.gather``; the blocks are
+    stacked in the group's rank order."""
     import torch
     import torch.distributed as dist
 
@@ -41,7 +43,7 @@ def _exchange(send, world, group, dst):
         buf = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
         dist.all_gather_into_tensor(buf, send, group=group)
         return buf
-    if dist.get_rank(group) == dst:
+    if dist.get_rank() == dst:                       # dst is a GLOBAL rank, as torch.distributed.gather takes it
         buf = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
         dist.gather(send, list(buf.view(world, send.shape[0], send.shape[1]).unbind(0)), dst=dst, group=group)
         return buf

@@ -338,6 +338,8 @@ def _local_search(residuals, pair, family, scipy_name):
         sol = optimize.least_squares(one, pair.value, bounds=(pair.lo, pair.hi))
         return sol.x
     if family == 'differential_evolution':                 # bounds as they are; a generation = one launch
+        # (a deliberate departure from lmfit, which runs it on the internal variables with updating='immediate',
+        # seed=None and polish=True: see minimize_parameters)
         def cost_columns(x):                               # SciPy hands over (2, S)
             r = residuals(np.ascontiguousarray(x.T))
             return np.nan_to_num((r * r).sum(axis=1), nan=np.inf)
@@ -398,6 +400,10 @@ def minimize_parameters(F2, F1, E, f_in0, vh_obs0, alt, b_mag, b_psi, method='br
     ``'differential_evolution'``, with lmfit's bounds transform and defaults restated from its documentation; every
     residual they ask for is evaluated by the fused kernel, several at once where the algorithm allows it.  lmfit is
     absent here, so the optimiser's path is parity-unpinned; the residuals are the pinned ones (G11).
+    ``'differential_evolution'`` is NOT lmfit's run of it: here the population lives in the external bounds, is
+    updated a generation at a time (one launch each), starts from seed 0 and is not polished; lmfit searches its
+    internal (arcsine) variables with immediate updating, an unseeded start and an L-BFGS-B polish of the best
+    member - expect the same basin, a coarser minimum and another path.
     """
     from copy import deepcopy
 

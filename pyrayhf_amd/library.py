@@ -445,7 +445,7 @@ def vertical_forward_operator(freq, den, bmag, bpsi, alt, mode='O', n_points=200
     frequency and leaves the others alone (the reference: NaN for 0 and NaN, a meaningless number for a
     negative frequency).  Profiles may have up to 65 535 levels; where the levels BELOW the density
     peak number more than 1400 they no longer fit the GPU's local memory and are staged in global
-    memory instead (about three times the time per grid point).
+    memory instead (1.1 - 1.4 times the time per grid point on long grids).
     """
     code = _mode_code(mode)
     if any(_is_torch(x) and x.is_cuda for x in (den, bmag, bpsi)):

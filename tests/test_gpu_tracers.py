@@ -9,12 +9,31 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
+def _midpoint_against_the_reference(x_mid, z_mid, x_mid_ref, z_mid_ref, x_ref, z_ref, rtol):
+    """The midpoint rule (reference library.py:1248-1252 / :1691-1695; prhf_snell.inc, in front of snell_ray): on the
+    mirrored path the running length behind the last up-leg segment IS half the path, so in exact arithmetic the
+    reference's search returns that segment's first node, the one before the apex - which is what the kernels return,
+    to the path nodes' tolerance.  The reference compares two roundings of the same number and lands on that node or
+    on the apex.  Returns whether the two agree; where they do the values are held to `rtol`."""
+    apex = x_ref.size // 2
+    assert apex >= 1
+    assert abs(x_mid - x_ref[apex - 1]) <= rtol * abs(x_ref[apex - 1]) + 1e-9
+    assert abs(z_mid - z_ref[apex - 1]) <= 1e-13 * abs(z_ref[apex - 1]) + 1e-12
+    on = [abs(x_mid_ref - x_ref[j]) <= 1e-14 * abs(x_ref[j]) and z_mid_ref == z_ref[j] for j in (apex - 1, apex)]
+    assert on[0] or on[1], (x_mid_ref, z_mid_ref, x_ref[apex - 1:apex + 1], z_ref[apex - 1:apex + 1])
+    if on[0]:
+        assert abs(x_mid - x_mid_ref) <= rtol * abs(x_mid_ref) + 1e-9
+        assert abs(z_mid - z_mid_ref) <= 1e-13 * abs(z_mid_ref) + 1e-12
+    return bool(on[0])
+
+
 @pytest.mark.parametrize("name", ["gauss", "day"])
 def test_batch_against_reference_rays(name):
     from pyrayhf_amd import tracers
     g = load_golden("g8_snell.npz")
     prof = [g[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
     rays, want, offs = g[f"{name}_rays"], g[f"{name}_scalars"], g[f"{name}_offsets"]
+    midpoints = []
     for mode_i, mode in enumerate("OX"):
         sel = np.nonzero(rays[:, 0] == mode_i)[0]
         r = tracers.trace_rays_cartesian_snells(rays[sel, 1], rays[sel, 2], *prof, mode, return_paths=True)
@@ -37,13 +56,14 @@ def test_batch_against_reference_rays(name):
             np.testing.assert_allclose(r["x"][k, :n], x_ref, rtol=1e-12, atol=1e-10)
             np.testing.assert_allclose(r["z"][k, :n], z_ref, rtol=1e-13, atol=1e-12)
             assert np.all(np.isnan(r["x"][k, n:]))
-            # the reference's midpoint is the first node whose cumulative length reaches half the path: by
-            # symmetry that is the apex or, one rounding away, the node before it
             apex = n // 2
-            assert any(abs(r["x_midpoint"][k] - x_ref[j]) <= 1e-9 * max(1.0, abs(x_ref[j])) for j in (apex - 1, apex))
-            assert any(abs(w[k, 2] - x_ref[j]) <= 1e-9 * max(1.0, abs(x_ref[j])) for j in (apex - 1, apex))
             np.testing.assert_allclose(r["z_turn_km"][k], z_ref[apex], rtol=1e-13)
             np.testing.assert_allclose(r["x_turn_km"][k], x_ref[apex], rtol=1e-12, atol=1e-10)
+            midpoints.append(_midpoint_against_the_reference(r["x_midpoint"][k], r["z_midpoint"][k], w[k, 2], w[k, 3],
+                                                             x_ref, z_ref, 1e-12))
+    # the reference's own choice between the two nodes (its rounding decides): the node before the apex for 84 of
+    # the 127 rays of G8, the apex for 43; where it is the node before, the values agree to the paths' 1e-12
+    assert sum(midpoints) >= 0.6 * len(midpoints), (sum(midpoints), len(midpoints))
 
 
 def test_single_ray_dict_like_the_reference():
@@ -89,6 +109,7 @@ def test_spherical_batch_against_reference_rays(name):
     p = load_golden("g8_snell.npz")
     prof = [p[f"{name}_{k}"] for k in ("alt", "den", "bmag", "bpsi")]
     rays, want, offs = g[f"{name}_rays"], g[f"{name}_scalars"], g[f"{name}_offsets"]
+    midpoints = []
     for mode_i, mode in enumerate("OX"):
         sel = np.nonzero(rays[:, 0] == mode_i)[0]
         r = tracers.trace_rays_spherical_snells(rays[sel, 1], rays[sel, 2], *prof, mode, return_paths=True)
@@ -104,8 +125,12 @@ def test_spherical_batch_against_reference_rays(name):
             n = offs[i + 1] - offs[i]
             assert r["n_path"][k] == n
             if n:
-                np.testing.assert_allclose(r["x"][k, :n], g[f"{name}_x"][offs[i]:offs[i + 1]], rtol=1e-11, atol=1e-9)
-                np.testing.assert_allclose(r["z"][k, :n], g[f"{name}_z"][offs[i]:offs[i + 1]], rtol=1e-13, atol=1e-12)
+                x_ref, z_ref = g[f"{name}_x"][offs[i]:offs[i + 1]], g[f"{name}_z"][offs[i]:offs[i + 1]]
+                np.testing.assert_allclose(r["x"][k, :n], x_ref, rtol=1e-11, atol=1e-9)
+                np.testing.assert_allclose(r["z"][k, :n], z_ref, rtol=1e-13, atol=1e-12)
+                midpoints.append(_midpoint_against_the_reference(r["x_midpoint"][k], r["z_midpoint"][k], w[k, 2],
+                                                                 w[k, 3], x_ref, z_ref, 1e-11))
+    assert sum(midpoints) >= 0.5 * len(midpoints), (sum(midpoints), len(midpoints))
 
 
 def test_spherical_single_ray_and_flat_limit():
@@ -134,9 +159,8 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
     """prhf_snell_fan_f64: the refractive-index levels once per (profile, frequency), read by every elevation of the
     fan.  Same levels, same bracket, same up-leg increments as the per-ray call - whose kernel (round 4) makes ONE pass
     over the levels and takes the mirrored half of the path by symmetry, where the fan kernel, with the table in reach,
-    walks the mirrored path as the reference does: the two agree to 1e-13 in every scalar and path node (measured
-    1e-15), the same rays turn, the paths have the same nodes; the midpoint - the first node at half the path, which
-    the reference's own rounding puts on the apex or on its neighbour - is the apex itself in the per-ray call.
+    walks the up-leg a second time: the two agree to 1e-13 in every scalar and path node (measured 1e-15), the same
+    rays turn, the paths have the same nodes, the midpoint is the same node (the one before the apex).
     Through the per-ray call's test both are held to the reference's rays (fixtures G8 / G9 are fans)."""
     from pyrayhf_amd import tracers
     g = load_golden("g8_snell.npz")
@@ -150,7 +174,8 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
             fan = fan_fn(freqs, elevs, *prof, mode, return_paths=True)
             ff, ee = np.meshgrid(freqs, elevs, indexing="ij")
             rays = ray_fn(ff.ravel(), ee.ravel(), *prof, mode, return_paths=True)
-            for key in ("group_path_km", "group_delay_sec", "ground_range_km", "x_turn_km", "z_turn_km", "n_path", "x", "z"):
+            for key in ("group_path_km", "group_delay_sec", "ground_range_km", "x_turn_km", "z_turn_km", "x_midpoint",
+                        "z_midpoint", "n_path", "x", "z"):
                 assert fan[key].shape[:2] == (freqs.size, elevs.size)
                 got, want = fan[key].reshape(rays[key].shape), rays[key]
                 assert np.array_equal(np.isnan(got), np.isnan(want)), (name, mode, key)
@@ -158,13 +183,11 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
                     assert np.array_equal(got, want), (name, mode, key)
                 else:
                     np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12, equal_nan=True, err_msg=f"{name} {mode} {key}")
-            # midpoints: the per-ray call's is the apex; the fan's the apex or a neighbour (the reference's search)
+            # midpoints: the node before the apex in both kernels (a path node: bit for bit the path array's entry)
             n_path = rays["n_path"]
-            fx = fan["x_midpoint"].reshape(n_path.shape)
             for k in np.nonzero(n_path > 0)[0]:
                 apex = int(n_path[k]) // 2
-                assert abs(rays["x_midpoint"][k] - rays["x"][k, apex]) <= 1e-12 * max(1.0, abs(rays["x"][k, apex]))
-                assert any(abs(fx[k] - rays["x"][k, j]) <= 1e-9 * max(1.0, abs(rays["x"][k, j])) for j in (apex - 1, apex, apex + 1))
+                assert rays["x_midpoint"][k] == rays["x"][k, apex - 1] and rays["z_midpoint"][k] == rays["z"][k, apex - 1]
             assert np.isfinite(fan["group_path_km"]).any() and np.isnan(fan["group_path_km"]).any()
     # several profiles: (P, F, E)
     two = [np.stack([g["gauss_den"], 0.5 * g["gauss_den"]]), np.stack([g["gauss_bmag"]] * 2), np.stack([g["gauss_bpsi"]] * 2)]
@@ -235,6 +258,7 @@ def test_random_rays_against_the_oracle(spherical):
     ofn = sn.trace_spherical if spherical else sn.trace_cartesian
     rtol = 1e-11 if spherical else 1e-12
     turned = 0
+    midpoints = []
     for mode in "OX":
         got = fn(f, e, alt, den, bmag, bpsi, mode, profile_index=idx, return_paths=True)
         for k in range(n):
@@ -256,4 +280,8 @@ def test_random_rays_against_the_oracle(spherical):
             assert got["n_path"][k] == m
             np.testing.assert_allclose(got["x"][k, :m], want["x"], rtol=rtol, atol=1e-9)
             np.testing.assert_allclose(got["z"][k, :m], want["z"], rtol=rtol, atol=1e-11)
+            midpoints.append(_midpoint_against_the_reference(got["x_midpoint"][k], got["z_midpoint"][k],
+                                                             want["x_midpoint"], want["z_midpoint"], want["x"],
+                                                             want["z"], rtol))
     assert turned > 100
+    assert sum(midpoints) >= 0.5 * len(midpoints), (sum(midpoints), len(midpoints))
