@@ -214,6 +214,8 @@ def extra_legs(torch, dev, ctx, library, synth, pdist, math):
             "roofline": {"bound": "fp64_valu", "achieved": aflops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": aflops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                          "traffic": rec.get("hbm_bytes_per_launch"), "traffic_key": key if rec else None,
+                         "traffic_source": (f"NOT measured in this run: replayed from profiles/hbm_traffic.json[{key}] "
+                                            f"({rec.get('source')})") if rec else None,
                          "algorithmic_bytes": abytes},
         }
         del tt, outs, integrated
@@ -235,6 +237,203 @@ def extra_legs(torch, dev, ctx, library, synth, pdist, math):
         "n_points=20000, one launch, seed 20260004 (profiles built on the device)", f4, alt, den, bmag, bpsi, [(0, 100000, "X", 20000)], 3, 1,
         "X_20000_100000x256")
     return legs
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0    # wave instructions per second: 1024 SIMDs, one FP64-rate VALU instruction per 4
+                                           # cycles, 2.4 GHz (MI355X_MICROARCH.md: 256 CUs, max clock 2400 MHz)
+
+
+def f_row_legs(torch, dev, ctx, library, synth):
+    """The rows SURVEY 8(f) marks "next", each with the bound it is priced against:
+      snell_per_ray / snell_fan   reference trace_ray_cartesian_snells / trace_ray_spherical_snells (library.py:1096-1268,
+                                  :1460-1713): rays/s; issue-bound - vector instructions per ray (from the committed profile,
+                                  profiles/f_row_bounds.json) x rays/s against the chip's FP64-rate issue slots
+      stage_ops                   find_mu_mup (:161-256), find_vh (:259-293), regrid_to_nonuniform_grid (:324-438) as
+                                  device ops on 2^26 elements: algorithmic bytes / kernel time against 8 TB/s
+      fit_brute                   the brute-force search of minimize_parameters (:794-798): 41 x 41 candidate profiles x 174
+                                  frequencies through prhf_vfo_residual_f64; nominal FP64 flops like config 3
+    Kernel times are the library's HIP events; about 2 s of wall time in all."""
+    from pyrayhf_amd import _native, fitting, tracers
+    bounds_path = os.path.join(ROOT, "profiles", "f_row_bounds.json")
+    bounds = json.load(open(bounds_path)) if os.path.exists(bounds_path) else {}
+    legs = {}
+
+    def issue_roofline(key, rays_per_s):
+        b = bounds.get(key)
+        if not b:
+            return {"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                    "frac": None, "traffic": None, "note": "no committed instruction count for this kernel yet"}
+        achieved = b["valu_per_ray"] * rays_per_s
+        return {"bound": "valu_issue", "achieved": achieved, "peak": VALU_ISSUE_PEAK, "unit": "wave-instructions/s",
+                "frac": achieved / VALU_ISSUE_PEAK, "valu_per_ray": b["valu_per_ray"], "traffic": b.get("hbm_bytes_per_launch"),
+                "traffic_source": f"NOT measured in this run: {b.get('source')}",
+                "note": "vector instructions per ray (SQ_INSTS_VALU / rays of the committed profile) x rays/s against 1024 SIMDs "
+                        "x 2.4 GHz / 4 cycles per FP64-rate instruction; v_rsq_f64 / v_rcp_f64 issue at a quarter of that rate"}
+
+    # ---- Snell's-law tracers: 200 000 random (frequency, elevation, profile) rays over 256 profiles, O mode -------------
+    alt, den, bmag, bpsi = synth.chapman_profiles(256, 7)
+    rng = np.random.default_rng(0)
+    n_rays = 200000
+    f = rng.uniform(2e6, 14e6, n_rays)
+    e = rng.uniform(5.0, 89.0, n_rays)
+    idx = rng.integers(0, 256, n_rays)
+    per_ray = {"workload": "200000 rays, random frequency 2-14 MHz, elevation 5-89 deg, one of 256 synthetic Chapman profiles "
+                           "(620 levels) each, O mode, one launch (host arrays in and out; kernel time from HIP events)"}
+    for name, fn in (("flat", tracers.trace_rays_cartesian_snells), ("spherical", tracers.trace_rays_spherical_snells)):
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = fn(f, e, alt, den, bmag, bpsi, "O", profile_index=idx)
+            wall = time.perf_counter() - t0
+            ms.append(ctx.last_kernel_ms())
+        k = min(ms[1:])
+        per_ray[name] = {"kernel_ms": k, "rays_per_s": n_rays / (k * 1e-3), "ms_per_call_wall": 1e3 * wall,
+                         "traced_fraction": float(np.isfinite(r["group_path_km"]).mean()),
+                         "roofline": issue_roofline(f"snell_per_ray_{name}", n_rays / (k * 1e-3))}
+    legs["snell_per_ray"] = per_ray
+    # ---- fans: 16 profiles x 100 frequencies x 128 elevations, the levels once per (profile, frequency) ------------------
+    fan_f, fan_e = np.linspace(2e6, 14e6, 100), np.linspace(5.0, 89.0, 128)
+    fan = {"workload": "16 profiles x 100 frequencies x 128 elevations = 204800 rays, O mode, grouped launch (refractive-index "
+                       "levels once per (profile, frequency))"}
+    for name, fn in (("flat", tracers.trace_fan_cartesian_snells), ("spherical", tracers.trace_fan_spherical_snells)):
+        ms = []
+        for _ in range(3):
+            r = fn(fan_f, fan_e, alt, den[:16], bmag[:16], bpsi[:16], "O")
+            ms.append(ctx.last_kernel_ms())
+        k, n_fan = min(ms[1:]), 16 * 100 * 128
+        fan[name] = {"kernel_ms": k, "rays_per_s": n_fan / (k * 1e-3),
+                     "traced_fraction": float(np.isfinite(r["group_path_km"]).mean()),
+                     "roofline": issue_roofline(f"snell_fan_{name}", n_fan / (k * 1e-3))}
+    legs["snell_fan"] = fan
+
+    # ---- stage ops on GPU-resident arrays (HBM-bound) ---------------------------------------------------------------------
+    DP = _native.FLAG_DEVICE_PTRS
+
+    def best(call, reps=4):
+        ms = []
+        torch.cuda.synchronize(dev)        # the operands were made on torch's stream; the ops run on the context's own
+        for _ in range(reps):
+            _native.raise_for(call())
+            ms.append(ctx.last_kernel_ms())
+        return min(ms[1:])
+
+    def hbm(bytes_moved, ms):
+        gbs = bytes_moved / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes": bytes_moved}
+    ops = {}
+    n = 1 << 26
+    X = torch.rand(n, dtype=torch.float64, device=dev) * 0.9
+    Y = torch.rand(n, dtype=torch.float64, device=dev) * 0.3 + 0.05
+    P = torch.rand(n, dtype=torch.float64, device=dev) * 90.0
+    mu, mup = torch.empty_like(X), torch.empty_like(X)
+    ctx.set_stream(0, borrow=False)
+    ctx.set_math(_native.MATH_FAST)
+    ms = best(lambda: ctx.mu_mup(X.data_ptr(), Y.data_ptr(), P.data_ptr(), n, 1, mu.data_ptr(), mup.data_ptr(), DP))
+    ops["find_mu_mup"] = {"workload": f"{n} elements, X mode, fast tier: 24 B read + 16 B written per element", "kernel_ms": ms,
+                          "elements_per_s": n / (ms * 1e-3), "roofline": hbm(40 * n, ms)}
+    del mu, mup
+    F, N = 4096, 16384                                   # 2^26 grid points
+    Xr, Yr, Pr = X.view(F, N), Y.view(F, N), P.view(F, N)
+    Dr = torch.rand(F, N, dtype=torch.float64, device=dev) * 0.01
+    vh = torch.empty(F, dtype=torch.float64, device=dev)
+    ms = best(lambda: ctx.find_vh(Xr.data_ptr(), Yr.data_ptr(), Pr.data_ptr(), Dr.data_ptr(), F, N, 80.0, 1, vh.data_ptr(), DP))
+    ops["find_vh"] = {"workload": f"({F}, {N}) arrays X, Y, psi, dh -> ({F},), X mode, fast tier: 32 B read per grid point",
+                      "kernel_ms": ms, "points_per_s": F * N / (ms * 1e-3), "roofline": hbm(32 * F * N, ms)}
+    del X, Y, P, Xr, Yr, Pr, Dr
+    torch.cuda.empty_cache()
+    a1, d1, b1, p1 = synth.chapman_profiles(1, 5)
+    F, N = 1024, 20000
+    fhz = torch.as_tensor(np.linspace(0.5, 16.0, F) * 1e6, device=dev)
+    tt = [torch.as_tensor(x, device=dev) for x in (d1[0], b1[0], p1[0], a1)]
+    mult = torch.as_tensor(library._multiplier(N), device=dev)
+    outs = [torch.empty(F, N, dtype=torch.float64, device=dev) for _ in range(7)] + [torch.empty(F, N, dtype=torch.int64, device=dev)]
+    ptrs = [o.data_ptr() for o in outs]
+    ms = best(lambda: ctx.regrid(fhz.data_ptr(), F, tt[0].data_ptr(), tt[1].data_ptr(), tt[2].data_ptr(), tt[3].data_ptr(),
+                                 a1.size, mult.data_ptr(), N, 1, ptrs, DP))
+    ops["regrid_to_nonuniform_grid"] = {"workload": f"1 profile x {F} frequencies x {N} points, X mode: eight (F, N) arrays written, "
+                                                    "64 B per grid point", "kernel_ms": ms, "points_per_s": F * N / (ms * 1e-3),
+                                        "roofline": hbm(64 * F * N, ms)}
+    del outs
+    torch.cuda.empty_cache()
+    ctx.set_math(_native.MATH_AUTO)
+    legs["stage_ops"] = ops
+
+    # ---- the brute-force search of minimize_parameters: a 41 x 41 grid of candidate layers, one launch ------------------
+    alt1 = np.arange(80.0, 700.0, 1.0)
+    hm = np.linspace(250.0, 350.0, 41)
+    hf = np.linspace(35.0, 70.0, 41)
+
+    def chapman(nm, h0, hs):
+        z = (alt1[None, :] - h0[:, None]) / hs[:, None]
+        return nm * np.exp(0.5 * (1.0 - z - np.exp(-z)))
+    hh, ss = (g.ravel() for g in np.meshgrid(hm, hf, indexing="ij"))
+    cand = chapman(8e11, hh, ss) + chapman(1.2e11, np.full(hh.size, 110.0), np.full(hh.size, 9.0))
+    bmag1 = 4.5e-5 * ((6371.0 + 80.0) / (6371.0 + alt1)) ** 3
+    bpsi1 = 40.0 + 0.001 * (alt1 - 80.0)
+    f1 = synth.sounder_frequencies(1)
+    true = cand[20 * 41 + 20]
+    vh_obs = library.vertical_forward_operator(f1, true, bmag1, bpsi1, alt1, "O", 200)
+    keep = np.isfinite(vh_obs)
+    fk, ok_ = f1[keep], vh_obs[keep]
+    tc = [torch.as_tensor(x, device=dev) for x in (fk, ok_, cand, bmag1, bpsi1, alt1)]
+    ms, walls = [], []
+    for _ in range(4):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _res, cost, vhm = fitting.residual_VH_batch(*tc, "O", 200, return_vh=True)
+        torch.cuda.synchronize(dev)
+        walls.append(time.perf_counter() - t0)
+        ms.append(ctx.last_kernel_ms())
+    best_node = int(torch.argmin(torch.nan_to_num(cost, nan=float("inf"))).item())
+    k = min(ms[1:])
+    integrated = torch.isfinite(vhm) & (vhm - float(alt1.min()) > 1e-9)
+    aflops = float(FLOPS_PER_POINT * 200 * integrated.sum() + (FLOPS_PER_LEVEL * torch.argmax(tc[2], dim=1).double() * fk.size).sum())
+    legs["fit_brute"] = {"workload": f"41 x 41 = {cand.shape[0]} candidate Chapman layers (hmF2 x scale height) x {fk.size} reflecting "
+                                     "frequencies of a 174-frequency sweep, O mode, n_points=200, shared field: ONE call of "
+                                     "prhf_vfo_residual_f64 (fused operator + residual rows + sums of squares), GPU-resident",
+                         "kernel_ms": k, "ms_per_call_wall": 1e3 * min(walls[1:]), "candidates_per_s": cand.shape[0] / (k * 1e-3),
+                         "integrals_per_s": cand.shape[0] * fk.size / (k * 1e-3), "best_node_is_the_generating_one": best_node == 20 * 41 + 20,
+                         "roofline": {"bound": "fp64_valu", "achieved": aflops / (k * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": aflops / (k * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                                      "note": "HIP events around the whole call: the fused operator over the candidates and the "
+                                              "residual kernel behind it; 1 681 blocks are 1.6 resident rounds of the short-grid "
+                                              "kernel: a launch this small is drain-bound"}}
+    return legs
+
+
+def host_buffer_leg(library, freq, alt, den, bmag, bpsi, mode, n_points, math, kernel_ms):
+    """A batch handed over as host NumPy buffers (pageable): H2D + kernel + D2H, wall time of the second call (the first
+    grows the library's staging arena).  PCIe-inclusive - never `value`."""
+    library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
+    walls = []
+    for _ in range(3):
+        t2 = time.perf_counter()
+        library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
+        walls.append(time.perf_counter() - t2)
+    dt = min(walls)
+    n_prof, n_freq = den.shape[0], freq.size
+    bytes_in = 8 * (3 * den.size + alt.size + freq.size)
+    bytes_out = 8 * n_prof * n_freq
+    return {"integrals_per_s": n_prof * n_freq / dt, "ms_per_call": 1e3 * dt, "h2d_bytes": bytes_in, "d2h_bytes": bytes_out,
+            "effective_h2d_gbs": bytes_in / dt / 1e9, "kernel_ms_resident": kernel_ms,
+            "ratio_to_resident_kernel": (1e3 * dt / kernel_ms) if kernel_ms else None,
+            "note": "PCIe-inclusive (pageable host memory in and out); never `value`; effective_h2d_gbs = input bytes / whole call"}
+
+
+def arm_watchdog(seconds, what, rank):
+    """A hung collective set-up must end with a message and a non-zero exit, not with the driver's time limit: after
+    `seconds` the process says what it was waiting for and leaves (os._exit: no exec, no re-launch)."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py rank {rank}: {what} did not finish within {seconds} s - giving up (exit 4)\n")
+        sys.stderr.flush()
+        os._exit(4)
+    timer = threading.Timer(seconds, fire)
+    timer.daemon = True
+    timer.start()
+    return timer
 
 
 def free_port():
@@ -380,27 +579,41 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = world > 1 or args.force_collective
+    world_seen = 1
     if collective:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    world_seen = dist.get_world_size() if collective else 1
-    if collective:
-        # Communicator set-up (RCCL builds its rings and its send/recv channels on first use: seconds) belongs to the
-        # environment, not to a step: one tiny exchange of each kind the steps use, whatever --warmup is.
-        side0 = dev if backend == "nccl" else torch.device("cpu")
-        tiny = torch.zeros((1, 8), dtype=torch.float64, device=side0)
-        pdist._exchange(tiny, world_seen, None, None)
-        pdist._exchange(tiny, world_seen, None, 0)
-        if backend == "nccl":
-            torch.cuda.synchronize(dev)
-        dist.barrier()
+        # The first N > 1 run on hardware must fail loudly, not hang: collectives time out after 120 s (the default is
+        # ten minutes - the driver's whole limit), a set-up that is still not through after 180 s ends the rank with a
+        # message, and an exception in it is reported with the rank and the backend before the non-zero exit.
+        limit = datetime.timedelta(seconds=120)
+        watchdog = arm_watchdog(180, f"process-group set-up ({backend}: init_process_group and the first gather / all-gather, "
+                                     f"world size {world})", rank)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=limit)
+            else:
+                dist.init_process_group(backend, timeout=limit)
+            world_seen = dist.get_world_size()
+            # Communicator set-up (RCCL builds its rings and its send/recv channels on first use: seconds) belongs to the
+            # environment, not to a step: one tiny exchange of each kind the steps use, whatever --warmup is.
+            side0 = dev if backend == "nccl" else torch.device("cpu")
+            tiny = torch.zeros((1, 8), dtype=torch.float64, device=side0)
+            pdist._exchange(tiny, world_seen, None, None)
+            pdist._exchange(tiny, world_seen, None, 0)
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+        except Exception as exc:           # noqa: BLE001
+            sys.stderr.write(f"bench.py rank {rank}/{world}: process-group set-up over {backend} failed: "
+                             f"{type(exc).__name__}: {exc}\n")
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog.cancel()
 
     math = {None: None, "faithful": _native.MATH_FAITHFUL, "fast": _native.MATH_FAST}[args.math]
     ctx = _native.context(local_rank)
@@ -609,12 +822,7 @@ def main():
         if world == 1 and not args.no_single_profile and local_segs is None:
             # the same batch handed over as host NumPy buffers (pageable): H2D + kernel + D2H
             # first call: the library's staging arena grows to this batch (hipMalloc); second call: steady state
-            library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
-            t2 = time.perf_counter()
-            library.vertical_forward_operator(freq, den, bmag, bpsi, alt, mode, n_points, math=math)
-            dt2 = time.perf_counter() - t2
-            result["host_buffers"] = {"integrals_per_s": p_gpu * n_freq / dt2, "ms_per_call": 1e3 * dt2,
-                                      "note": "PCIe-inclusive (pageable host memory in and out); never `value`"}
+            result["host_buffers"] = host_buffer_leg(library, freq, alt, den, bmag, bpsi, mode, n_points, math, k_ms)
 
         if world == 1 and not args.no_legs and args.workload == "config4" and args.profiles is None:
             # The other BASELINE configurations that fit one GPU, timed by the same process right behind the headline
@@ -625,6 +833,39 @@ def main():
                 t.pop(k)
             torch.cuda.empty_cache()
             result.update(extra_legs(torch, dev, ctx, library, synth, pdist, math))
+            # config 3 from NumPy arrays: 149 MB in, 14 MB out around a half-millisecond kernel - the drop-in rate of a
+            # short-grid batch is PCIe's
+            a3, d3, b3, p3 = synth.chapman_profiles(10000, 20260003)
+            result["host_buffers_config3"] = host_buffer_leg(library, synth.sounder_frequencies(3), a3, d3, b3, p3, "O", 200, math,
+                                                             result["config3"]["ms"])
+            del a3, d3, b3, p3
+            try:
+                result.update(f_row_legs(torch, dev, ctx, library, synth))
+            except Exception as exc:   # noqa: BLE001 - a failure in a row marked "next" must not sink the headline line
+                result["f_row_legs_error"] = f"{type(exc).__name__}: {exc}"
+
+        n_visible = torch.cuda.device_count()
+        if world == 1 and n_visible > 1 and not args.no_legs and args.workload == "config4" and args.profiles is None:
+            # More than one GPU visible to a single process: the drop-in call's own multi-GPU path (devices="all": one
+            # host thread and one context per GPU, contiguous row blocks, no process group, no collective) on config 4's
+            # rows, 12 500 per GPU, from NumPy arrays.  PCIe-inclusive; beside the RCCL ranks' figure, never `value`.
+            try:
+                rows_all = 12500 * n_visible
+                a_t, d_t, b_t, p_t = synth.chapman_profiles_torch(max(rows_all, 100000), 20260004, dev, rows=slice(0, rows_all))
+                host = [x.cpu().numpy() for x in (d_t, b_t, p_t)]
+                del d_t, b_t, p_t
+                f4 = synth.sounder_frequencies(4)
+                library.vertical_forward_operator(f4, *host, a_t.cpu().numpy(), "X", 20000, devices="all")    # arenas grow
+                t3 = time.perf_counter()
+                library.vertical_forward_operator(f4, *host, a_t.cpu().numpy(), "X", 20000, devices="all")
+                dt3 = time.perf_counter() - t3
+                result["devices_all"] = {"gpus": n_visible, "profiles": rows_all, "ms_per_call": 1e3 * dt3,
+                                         "integrals_per_s": rows_all * f4.size / dt3,
+                                         "note": "vertical_forward_operator(..., devices='all') on NumPy arrays: in-process threads, "
+                                                 "one per GPU; PCIe-inclusive; never `value`"}
+                del host
+            except Exception as exc:       # noqa: BLE001
+                result["devices_all"] = {"error": f"{type(exc).__name__}: {exc}"}
 
         if world == 1 and not args.no_cpu_baseline:
             # bounded samples of the same workload (for config 5: its X/20000 slice, where the CPU time goes)

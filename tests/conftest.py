@@ -15,6 +15,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# `pytest -x` stops at the first failure: the hot path's parity tests (SURVEY 8 rows a, b', e) come first, the rows
+# SURVEY marks "next" (stage ops, tracers, fitting driver) and the random sweeps after them, so that a failure in a
+# caller of the path never leaves the path itself untested.  Files not named here keep their alphabetical place.
+GPU_ORDER = ["test_gpu_parity", "test_gpu_reference_rows", "test_gpu_full_size", "test_gpu_host_batches",
+             "test_gpu_rccl", "test_gpu_knobs", "test_gpu_launch_knobs", "test_gpu_stage_ops", "test_gpu_abi_contracts",
+             "test_gpu_tracers", "test_gpu_fitting", "test_gpu_random"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(GPU_ORDER)}
+
+    def key(item):
+        module = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return rank.get(module, len(rank) if module.startswith("test_gpu") else -1)
+    items.sort(key=key)                 # stable: the order inside a file is untouched
+
+
 def apply_test_options():
     """PRHF_TEST_OPTIONS="name=value,..." (set by the tests that re-run a subset under other launch settings):
     applied through the library's explicit option call - the library itself reads no environment variable."""

@@ -108,3 +108,25 @@ def assert_o_mode(got, want, noise=None, factor=NOISE_FACTOR, min_within=MIN_WIT
         assert int((err[ok] > O_TOL).sum()) <= allowed, (f"{int((err[ok] > O_TOL).sum())} of {n_ok} finite pairs beyond 1e-6 "
                                                         f"(allowed {allowed}; {frac:.4f} within)")
     return float(err.max(initial=0.0))
+
+
+def assert_o_mode_reference_noise_alone(got, want, reference_noise, allowed_beyond, ceiling=1e-5, min_within=None):
+    """SURVEY.md 8(d)'s rule as written: |gpu - ref| <= max(1e-6, 4 x the REFERENCE's recorded input-jitter noise) per
+    pair - nothing made with the oracle in the floor - as a COUNT: at most `allowed_beyond` finite pairs may lie beyond
+    it (the pairs only the rounding noise explains: NumPy's pow is one ulp off where an exactly rounding
+    implementation is not), each of them below `ceiling`.  A regression of the exactly rounded
+    sin / cos / pow path (prhf_crmath.h) cannot hide behind an oracle-made floor here.  Returns (count, worst)."""
+    assert_masks(got, want)
+    err, ok = rel_err(got, want)
+    floor = np.asarray(reference_noise, dtype=np.float64)
+    if floor.ndim > want.ndim:
+        floor = floor.reshape(want.shape)
+    limit = np.minimum(LIMIT_CAP, np.maximum(O_TOL, NOISE_FACTOR * effective_noise(np.broadcast_to(floor, want.shape))))
+    beyond = ok & (err > limit)
+    count, worst = int(beyond.sum()), float(err[beyond].max(initial=0.0))
+    assert count <= allowed_beyond and worst <= ceiling, (
+        f"{count} pairs beyond max(1e-6, 4 x reference noise) (allowed {allowed_beyond}); worst of them {worst:.3e} "
+        f"(ceiling {ceiling:g}) at {np.argwhere(beyond)[:5].tolist()}")
+    if min_within is not None and ok.any():
+        assert (err[ok] <= O_TOL).mean() >= min_within, float((err[ok] <= O_TOL).mean())
+    return count, worst

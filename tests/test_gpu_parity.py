@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import assert_masks, assert_o_mode, assert_x_mode, combined_noise, oracle_noise, rel_err
+from parity import (assert_masks, assert_o_mode, assert_o_mode_reference_noise_alone, assert_x_mode, combined_noise,
+                    oracle_noise, rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +111,29 @@ def test_config3_rows_against_the_reference_noise_alone_g10(lib):
         beyond = ok & (err > limit)
         assert int(beyond.sum()) <= 2 and err[beyond].max(initial=0.0) <= 1e-5, (math, int(beyond.sum()), err[beyond])
         assert (err[ok] <= 1e-6).mean() >= 0.998, (math, (err[ok] <= 1e-6).mean())
+
+
+@pytest.mark.parametrize("which", ["Day", "Night"])
+@pytest.mark.parametrize("n_points", [200, 2000, 20000])
+def test_day_night_against_the_reference_noise_alone_g4(lib, which, n_points):
+    """G4's O-mode rows under SURVEY 8(d)'s rule as written (the reference's recorded noise alone in the floor), as a
+    count: NO pair beyond it, in the default and in the reference-order arithmetic (measured: worst pair 1.5e-6 on
+    Day, inside 4 x its recorded noise; 3.7e-8 ... 1.7e-7 on Night)."""
+    g = load_golden("g4_day_night.npz")
+    for math in (None, lib.MATH_FAITHFUL):
+        vh = lib.vertical_forward_operator(g["freq"], g[f"{which}_den"], g[f"{which}_bmag"], g[f"{which}_bpsi"],
+                                           g[f"{which}_alt"], "O", n_points, math=math)
+        assert_o_mode_reference_noise_alone(vh, g[f"{which}_O_{n_points}_vh"], g[f"{which}_O_{n_points}_noise"],
+                                            allowed_beyond=0, min_within=0.99)
+
+
+def test_chapman_batch_against_the_reference_noise_alone_g5(lib):
+    """G5's O/200 rows (64 seeded Chapman profiles, 5 584 finite pairs): no pair beyond the reference's own noise
+    rule (measured: worst 3.9e-6, inside 4 x its recorded noise), 99.9 % within 1e-6 outright."""
+    g = load_golden("g5_chapman64.npz")
+    for math in (None, lib.MATH_FAITHFUL):
+        vo = lib.vertical_forward_operator(g["freq"], g["den"], g["bmag"], g["bpsi"], g["alt"], "O", 200, math=math)
+        assert_o_mode_reference_noise_alone(vo, g["O_200_vh"], g["O_200_noise"], allowed_beyond=0, min_within=0.999)
 
 
 @pytest.mark.parametrize("math", ["faithful", "fast"])

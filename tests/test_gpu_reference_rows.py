@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import assert_o_mode, assert_x_mode, combined_noise
+from parity import assert_o_mode, assert_o_mode_reference_noise_alone, assert_x_mode, combined_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -79,3 +79,23 @@ def test_config5_rows_alone_inside_the_shard_and_inside_a_mixed_list_g15(lib):
     for (l0, _l1, mode, n) in local:
         assert np.array_equal(rows[l0: l0 + 8], g[f"{mode}_{n}_rows"])
         _check_slice(shard[l0: l0 + 8], g, mode, n, "shard")
+
+
+# pairs that may lie beyond max(1e-6, 4 x the reference's recorded noise) per O-mode slice of G15 - the ones only the
+# rounding noise (NumPy's one-ulp pow) explains; measured on the GPU and fixed here so that a regression shows up
+G15_BEYOND_REFERENCE_NOISE = {200: 8, 2000: 8}
+
+
+@pytest.mark.parametrize("n_points", [200, 2000])
+def test_config5_o_rows_against_the_reference_noise_alone_g15(lib, n_points):
+    """G15's O/200 and O/2000 rows (8 rows x 512 frequencies of config 5 each) under SURVEY 8(d)'s rule as written:
+    the limit comes from the reference's recorded `*_noise` alone, the exceptions are counted and each stays below
+    1e-5.  Default and reference-order arithmetic."""
+    g = load_golden("g15_config5_rows.npz")
+    for math in (None, lib.MATH_FAITHFUL):
+        got = lib.vertical_forward_operator(g["freq"], g[f"O_{n_points}_den"], g[f"O_{n_points}_bmag"],
+                                            g[f"O_{n_points}_bpsi"], g["alt"], "O", n_points, math=math)
+        count, worst = assert_o_mode_reference_noise_alone(got, g[f"O_{n_points}_vh"], g[f"O_{n_points}_noise"],
+                                                           allowed_beyond=G15_BEYOND_REFERENCE_NOISE[n_points],
+                                                           min_within=0.99)
+        print(f"G15 O/{n_points} math={math}: {count} pairs beyond the reference-noise rule, worst of them {worst:.2e}")

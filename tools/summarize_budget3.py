@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""gpurun_out/budget3_<tag>/ (tools/inst_budget3.sh) -> profiles/<tag>_config3_budget.md: per variant of
+tools/inst_budget3.py the kernel's time and instruction counters (last repetition of each variant), and the split of
+config 3's instructions and time into staging, list, per-item work, loop and queue that the differences give.
+
+    python tools/summarize_budget3.py gpurun_out/budget3_r05 r05
+"""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "vfo_short_kernel<256"
+
+
+def newest(paths):
+    by_dir = {}
+    for p in paths:
+        d = os.path.dirname(p)
+        if d not in by_dir or os.path.getmtime(p) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = p
+    return sorted(by_dir.values())
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    variants = [json.loads(l) for l in open(os.path.join(src, "variants.jsonl")) if l.startswith("{")]
+    reps = variants[0]["reps"]
+    rows = [dict(v) for v in variants]
+    # kernel trace: durations of the selected kernel's dispatches in order
+    tr = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")))
+    if tr:
+        d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+             for r in csv.DictReader(open(tr[0])) if KERNEL in r["Kernel_Name"]]
+        d = [x[1] for x in sorted(d)]
+        if len(d) == reps * len(rows):
+            for i, r in enumerate(rows):
+                r["trace_ms"] = min(d[i * reps + 1:(i + 1) * reps])
+    counters = []
+    for path in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+        per = {}
+        for r in csv.DictReader(open(path)):
+            if KERNEL in r["Kernel_Name"]:
+                per.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for name, vals in per.items():
+            vals = [v for _, v in sorted(vals)]
+            if len(vals) == reps * len(rows):
+                counters.append(name)
+                for i, r in enumerate(rows):
+                    r[name] = vals[(i + 1) * reps - 1]
+    lines = [f"# Instruction budget of `vfo_short_kernel<256>` on config 3 (`{tag}`)", "",
+             "Source: `tools/inst_budget3.sh` on one MI355X - `tools/inst_budget3.py` (10 000 profiles x 174 frequencies, O mode; one "
+             f"launch per variant, {reps} repetitions, the last one counted) under `rocprofv3 --kernel-trace` and under "
+             "`--pmc` passes of their own.  Wave-level instruction counts per launch.", "",
+             "| variant | kernel ms | VALU | SALU | LDS | trans f64 | VALU busy | waves/SIMD |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        ms = r.get("trace_ms", r["kernel_ms"])
+        busy = occ = float("nan")
+        if "SQ_ACTIVE_INST_VALU" in r and "GRBM_GUI_ACTIVE" in r:
+            cyc = r["GRBM_GUI_ACTIVE"] / 8.0
+            busy = r["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc
+            occ = r.get("SQ_WAVE_CYCLES", float("nan")) * 4 / 1024 / cyc
+        lines.append(f"| {r['variant']} | {ms:.4f} | {r.get('SQ_INSTS_VALU', float('nan')):.4g} | {r.get('SQ_INSTS_SALU', float('nan')):.4g} | "
+                     f"{r.get('SQ_INSTS_LDS', float('nan')):.4g} | {r.get('SQ_INSTS_VALU_TRANS_F64', float('nan')):.4g} | {busy:.3f} | {occ:.2f} |")
+    lines.append("")
+    by = {r["variant"].split(" (")[0].split(":")[0]: r for r in rows}
+    def get(prefix):
+        for r in rows:
+            if r["variant"].startswith(prefix):
+                return r
+        return None
+    one, esc, n2, n18, n34, n66, n130, full, noq, n392 = (get(p) for p in (
+        "one escaping", "174 escaping", "config 3 at n_points = 2", "n_points = 18", "n_points = 34", "n_points = 66",
+        "n_points = 130", "config 3: n_points = 200", "config 3, no point queued", "n_points = 392"))
+    if all(x is not None and "SQ_INSTS_VALU" in x for x in (one, esc, n2, n18, n34, n66, n130, full, noq, n392)):
+        P = 10000.0
+        v = lambda r: r["SQ_INSTS_VALU"] / P
+        per_iter = (v(n392) - v(full)) / 12.0
+        items = None
+        lines += ["## Split of config 3's VALU instructions (per profile, wave instructions)", "",
+                  f"* a wave-iteration of the checked main loop, all items of a profile together: (n = 392 minus n = 200) / 12 = "
+                  f"**{per_iter:.0f}** per profile and wave-iteration",
+                  f"* staging (argmax, nodes, running maximum) + one pass of the list: **{v(one):.0f}**",
+                  f"* the candidate list over 174 frequencies: + **{v(esc) - v(one):.0f}**",
+                  f"* items at n_points = 2 - per-item set-up, the last wave-iteration, reductions, queue bookkeeping, the queue's "
+                  f"entries (one per pair: the point at the reflection height), the final sums: + **{v(n2) - v(esc):.0f}**",
+                  f"* the 12 wave-iterations in front of the last one at n_points = 200: **{v(full) - v(n2):.0f}** "
+                  f"(of which what the queue adds over n_points = 2: {v(full) - v(noq):.0f} = default minus `well_conditioned = 0`, "
+                  f"which queues nothing at all)",
+                  f"* total **{v(full):.0f}** per profile = {full['SQ_INSTS_VALU']:.4g} per launch", ""]
+        t = lambda r: r.get("trace_ms", r["kernel_ms"])
+        lines += ["## The same split in time (ms per launch; phases overlap across the four workgroups of a CU, so the differences are "
+                  "what a phase ADDS to the launch, not what it would take alone)", "",
+                  f"* staging + one list pass {t(one):.3f}; + list over 174 frequencies {t(esc) - t(one):+.3f}; + items at n_points = 2 "
+                  f"{t(n2) - t(esc):+.3f}; + the loop up to n_points = 200 {t(full) - t(n2):+.3f} (no queue: {t(noq):.3f}); "
+                  f"per wave-iteration beyond 200 points {(t(n392) - t(full)) / 12 * 1e3:.1f} us", ""]
+    out = os.path.join(ROOT, "profiles", f"{tag}_config3_budget.md")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
