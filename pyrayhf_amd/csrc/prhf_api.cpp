@@ -45,6 +45,7 @@ constexpr size_t kPackBytes = 1u << 20;
 constexpr size_t kSlabMinBytes = 16u << 20;    // host-buffer batches from this many input bytes on go in slabs (run_host_slabs)
 constexpr size_t kDirectBytes = 128u << 10;   // inputs up to this size are written by the CPU through the BAR (direct_upload)
 
+constexpr int kStatusWords = 12;           // prhf_ctx::d_status: block queues and scratch words of the launches
 constexpr long long kMaxAlt = 1400;        // nodes + hints must fit 160 KiB of LDS
 constexpr long long kMaxAltTall = 65535;   // taller profiles are staged in global memory (vfo_tall_kernel); level
                                            // indices travel as uint16 in the hint table
@@ -557,6 +558,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     //  so no later launch or stream switch needs its end event either)
     const bool timed_launch = dev || kn.timing != 0;
     if (timed_launch) HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
+    bool zeroed_by_table = false;              // the control words below were zeroed by the per-frequency table's kernel
     if (want_pairs && grid) {
         if (!grid->pairs_ready) {
             if ((rc = ensure(c, grid->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
@@ -583,8 +585,36 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         // launch - one profile - is latency bound: it does without the extra kernel)
         if (n_prof * n_freq >= 4096) {
             if ((rc = ensure(c, c->ftab, ((size_t)n_freq + 1) * 64)) != PRHF_OK) return rc;
-            HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), c->stream));
+            // The table's kernel zeroes, on the way, every control word the launches behind it count in: the block
+            // queues and - their buffers sized here, as launch_short_kind sizes them again - the heads of the short-grid
+            // kernels' lists and the classes of the block order.  One memset each, they were six operations on the stream
+            // in front of a short-grid launch (config 3: ~25 us of 530).
+            prhf::ZeroWords zero;
+            std::memset(&zero, 0, sizeof zero);
+            auto zero_head = [&](DevBuf& b, size_t bytes, int words) -> int {
+                int rcz = ensure(c, b, bytes);
+                if (rcz != PRHF_OK) return rcz;
+                zero.p[zero.n] = static_cast<unsigned*>(b.p);
+                zero.words[zero.n++] = words;
+                return PRHF_OK;
+            };
+            zero.p[zero.n] = c->d_status;
+            zero.words[zero.n++] = kStatusWords;
+            for (int xmode = 0; xmode < 2; ++xmode) {
+                long long kind_blocks = 0;
+                for (int i = 0; i < (xmode ? n_shortx : n_short); ++i)
+                    kind_blocks += (xmode ? shortx_seg : short_seg)[i].prof_end - (xmode ? shortx_seg : short_seg)[i].prof_begin;
+                if (kind_blocks == 0 || kind_blocks > 0x7fffffffLL) continue;
+                const size_t list_bytes = (size_t)(kind_blocks + 1) * sizeof(unsigned);
+                if ((rc = zero_head(xmode ? c->leftover_x : c->leftover, list_bytes, 1)) != PRHF_OK) return rc;
+                if ((rc = zero_head(xmode ? c->leftover_tall_x : c->leftover_tall, list_bytes, 1)) != PRHF_OK) return rc;
+                if (!xmode && kn.short_order != 0 &&
+                    (rc = zero_head(c->order, PRHF_ORDER_CLASSES * (size_t)(kind_blocks + 1) * sizeof(unsigned), PRHF_ORDER_CLASSES)) != PRHF_OK)
+                    return rc;
+            }
+            HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), zero, c->stream));
             a.ftab = static_cast<const double*>(c->ftab.p);
+            zeroed_by_table = true;
         }
     }
 #ifdef PRHF_TRACE
@@ -606,7 +636,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     }
     // the launches' block queues: words 0 - 5, and word 8 for the second launch of the X-mode short grids (words 6 and 7
     // belong to the tracers and the peak pre-pass).  A launch without a queue - the single profile - enqueues neither.
-    if (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots)) {
+    if (!zeroed_by_table && (n_short > 0 || n_shortx > 0 || ((kPersistent || tall) && blocks > wg_slots))) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 6 * sizeof(unsigned), c->stream));
         if (n_shortx > 0) HIP_TRY(hipMemsetAsync(c->d_status + 8, 0, sizeof(unsigned), c->stream));
     }
@@ -671,7 +701,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         int rcl;
         if ((rcl = ensure(c, left, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
         as.leftover = static_cast<unsigned*>(left.p);
-        HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
+        if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(as.leftover, 0, sizeof(unsigned), short_stream));
         if (xmode) {
             // the compact geometry of the O kernel (four 4-wave workgroups per CU, staged arrays for as many levels as a
             // quarter of the LDS holds), taken on the same condition; a profile that peaks above them goes on a block
@@ -688,7 +718,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             if (second_x) {
                 if ((rcl = ensure(c, c->leftover_tall_x, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
                 as.leftover_tall = static_cast<unsigned*>(c->leftover_tall_x.p);
-                HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
+                if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
             }
             const size_t lds = prhf::shortx_lds_bytes(as.lds_levels, n_freq);
             const long long short_slots = (long long)c->cu_count * (Lx > 0 ? PRHF_COMPACT_WGS_PER_CU : (lds <= lds_half ? 2 : 1));
@@ -717,7 +747,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             if (second) {
                 if ((rcl = ensure(c, c->leftover_tall, (size_t)(short_blocks + 1) * sizeof(unsigned))) != PRHF_OK) return rcl;
                 as.leftover_tall = static_cast<unsigned*>(c->leftover_tall.p);
-                HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
+                if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
             }
             const int threads = compact ? PRHF_COMPACT_THREADS : PRHF_SHORT_THREADS;
             const int queue_entries = compact ? compact_queue : short_queue;
@@ -736,7 +766,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 const size_t words = PRHF_ORDER_CLASSES * (size_t)(short_blocks + 1);
                 if ((rcl = ensure(c, c->order, words * sizeof(unsigned))) != PRHF_OK) return rcl;
                 unsigned* order = static_cast<unsigned*>(c->order.p);
-                HIP_TRY(hipMemsetAsync(order, 0, PRHF_ORDER_CLASSES * sizeof(unsigned), short_stream));
+                if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(order, 0, PRHF_ORDER_CLASSES * sizeof(unsigned), short_stream));
                 HIP_TRY(prhf::launch_short_order(as, order, short_stream));
                 as.order = order;
             }
@@ -950,11 +980,11 @@ int prhf_ctx_create(int device, prhf_ctx** out) {
         (e = create_events_untimed(c->slab_done, 3)) != hipSuccess ||
         (e = create_events(c->ring0, prhf_ctx::kTimingRing)) != hipSuccess ||
         (e = create_events(c->ring1, prhf_ctx::kTimingRing)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), 12 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_status), kStatusWords * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_status), PRHF_STATUS_WORDS * sizeof(unsigned),
                            hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_status_dev), c->h_status, 0)) != hipSuccess ||
-        (e = hipMemset(c->d_status, 0, 12 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_status, 0, kStatusWords * sizeof(unsigned))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), kPackBytes, hipHostMallocMapped | hipHostMallocCoherent)) !=
             hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_pack_dev), c->h_pack, 0)) != hipSuccess ||
@@ -1332,6 +1362,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     a.path_stride = path_x ? path_stride : 0;
     a.mode = mode == PRHF_MODE_O ? PRHF_KMODE_O : PRHF_KMODE_X;
     a.geometry = geo.geometry;
+    a.reduced = (c->math == PRHF_MATH_FAITHFUL) ? 0 : 1;        // (grouped launches read faithful level tables either way)
     a.earth_radius_km = geo.earth_radius_km;
     a.dz_target_km = geo.dz_target_km;
     a.apex_boost = geo.apex_boost;

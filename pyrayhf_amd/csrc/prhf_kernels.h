@@ -170,7 +170,14 @@ hipError_t query_occupancy(int tier, size_t lds_bytes, int* blocks_per_cu);
 // pairs[2 i], pairs[2 i + 1] = mult[i], mult[i + 1] - mult[i]; `pairs` holds n + PRHF_PAIR_PAD entries
 hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hipStream_t stream);
 // tab[8 f ..] = f_hz, f2, cp^2/f2, (g_p/f)^2, 1/f2, 1/f_hz, 0, 0; row n_freq: min |freq_mhz| (tab holds n_freq + 1 rows)
-hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream);
+// Control words that the per-frequency table's kernel zeroes on the way (its workgroup 0): the block queues and list
+// heads of the launches that follow it on the stream.
+struct ZeroWords {
+    unsigned* p[8];
+    int words[8];
+    int n;
+};
+hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, const ZeroWords& zero, hipStream_t stream);
 // tier: 0 faithful, 1 fast, 2 per slice (SegDev::tier)
 // a.n_blocks blocks of work; with a.queue set the grid is `grid_blocks` persistent workgroups that pull
 // block indices from the queue, else grid_blocks must equal a.n_blocks
@@ -253,6 +260,8 @@ struct SnellArgs {
     unsigned* status;
     long long n_rays, n_alt, prof_stride, alt_stride, path_stride;
     int mode;
+    int reduced;                 // per-ray launch: levels far from reflection and from the ray's turning point in the reduced
+                                 // algebra (the default; 0: every level in the reference's operation order) - prhf_snell.inc
     int geometry;                // 0 flat Earth, 1 spherical Earth
     double earth_radius_km;      // spherical only (library.py:1473, :1552-1553)
     double dz_target_km;         // spherical sub-step controls (library.py:1470-1472)
@@ -261,7 +270,7 @@ struct SnellArgs {
 };
 hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
 // wavefronts of the per-ray kernel that one device keeps resident; cu_count: multiprocessors of the device
-hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false);
+hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false, bool reduced = false);
 
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,

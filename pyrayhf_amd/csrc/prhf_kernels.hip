@@ -2057,25 +2057,30 @@ hipError_t launch_grid_pairs(const double* mult, long long n, double* pairs, hip
 }
 
 // Per-frequency scalars of a launch (PairFreq): row f = {f_hz, f2, cX, cY2, 1/f2, 1/f_hz, 0, 0}.
-__global__ void freq_table_kernel(const double* __restrict__ freq_mhz, long long n_freq, double* __restrict__ tab) {
+__global__ __launch_bounds__(256) void freq_table_kernel(const double* __restrict__ freq_mhz, long long n_freq,
+                                                         double* __restrict__ tab, const ZeroWords zero) {
 #pragma clang fp contract(off)
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_freq) return;
-    // A frequency that is not a positive finite number is carried as NaN: every comparison of the level search then
-    // fails and the column comes out NaN (the reference: NaN for 0 and NaN, something meaningless for f < 0).
-    const double fm = freq_mhz[f];
-    const double f_hz = (fm > 0.0 && fm < __builtin_inf()) ? fm * 1e6 : qnan();       // :491
-    const double f2 = f_hz * f_hz;                             // f**2
-    const double cY = kGyro / f_hz;
-    double* row = tab + 8 * f;
-    row[0] = f_hz; row[1] = f2; row[2] = (kPlasma * kPlasma) / f2; row[3] = cY * cY;
-    row[4] = 1.0 / f2; row[5] = 1.0 / f_hz; row[6] = 0.0; row[7] = 0.0;
-}
-
-// Row n_freq of the table: min |freq_mhz| over the launch (the isotropic test of library.py:201 needs the lowest
-// frequency; the short-grid kernel reads it here instead of scanning the frequencies once per profile) and, in
-// its second word, the largest finite |freq_mhz| (short_order_kernel's scale).
-__global__ void freq_min_kernel(const double* __restrict__ freq_mhz, long long n_freq, double* __restrict__ tab) {
+    if (f < n_freq) {
+        // A frequency that is not a positive finite number is carried as NaN: every comparison of the level search then
+        // fails and the column comes out NaN (the reference: NaN for 0 and NaN, something meaningless for f < 0).
+        const double fm = freq_mhz[f];
+        const double f_hz = (fm > 0.0 && fm < __builtin_inf()) ? fm * 1e6 : qnan();       // :491
+        const double f2 = f_hz * f_hz;                             // f**2
+        const double cY = kGyro / f_hz;
+        double* row = tab + 8 * f;
+        row[0] = f_hz; row[1] = f2; row[2] = (kPlasma * kPlasma) / f2; row[3] = cY * cY;
+        row[4] = 1.0 / f2; row[5] = 1.0 / f_hz; row[6] = 0.0; row[7] = 0.0;
+    }
+    if (blockIdx.x != 0) return;
+    // Workgroup 0 alone: the control words that the launches behind this one count in - block queues, the heads of the
+    // short-grid kernels' lists, the classes of the block order - are zeroed here instead of by one memset each (a
+    // short-grid launch had six of them in front of it: 25 us of a 530 us launch) ...
+    for (int k = 0; k < zero.n; ++k)
+        for (int i = threadIdx.x; i < zero.words[k]; i += blockDim.x) zero.p[k][i] = 0u;
+    // ... and row n_freq of the table: min |freq_mhz| over the launch (the isotropic test of library.py:201 needs the
+    // lowest frequency; the short-grid kernels read it here instead of scanning the frequencies once per profile) and,
+    // in its second word, the largest finite |freq_mhz| (short_order_kernel's scale).
     __shared__ double part[4];
     __shared__ double part_max[4];
     double fm = __builtin_inf(), fx = 0.0;
@@ -2128,13 +2133,10 @@ hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_a
     return hipGetLastError();
 }
 
-hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, hipStream_t stream) {
+hipError_t launch_freq_table(const double* freq_mhz, long long n_freq, double* tab, const ZeroWords& zero, hipStream_t stream) {
     if (n_freq <= 0) return hipSuccess;
     hipLaunchKernelGGL(freq_table_kernel, dim3((unsigned)((n_freq + 255) / 256)), dim3(256), 0, stream, freq_mhz, n_freq,
-                       tab);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(freq_min_kernel, dim3(1), dim3(256), 0, stream, freq_mhz, n_freq, tab);
+                       tab, zero);
     return hipGetLastError();
 }
 

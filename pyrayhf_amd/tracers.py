@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from .library import _as_rows, constants
+from .library import MATH_AUTO, _as_rows, constants
 
 __all__ = ["trace_ray_cartesian_snells", "trace_rays_cartesian_snells", "trace_ray_spherical_snells",
            "trace_rays_spherical_snells", "trace_fan_cartesian_snells", "trace_fan_spherical_snells",
@@ -26,7 +26,7 @@ _DICT_KEYS = ("x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_mid
 
 
 def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths, device,
-                controls=None):
+                controls=None, math=None):
     if mode not in ("O", "X"):
         raise ValueError("Mode must be O or X")                     # find_mu_mup, reference library.py:225-226
     f, e = np.broadcast_arrays(np.asarray(f0_Hz, dtype=np.float64), np.asarray(elevation_deg, dtype=np.float64))
@@ -49,6 +49,7 @@ def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, p
     px = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
     pz = np.empty((f.size, stride), dtype=np.float64) if return_paths else None
     ctx = _native.host_context(device)
+    ctx.set_math(MATH_AUTO if math is None else int(math))
     common = (f.ctypes.data, e.ctypes.data, idx.ctypes.data if idx is not None else None, f.size, d2.ctypes.data,
               b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof, n_alt, n_alt if a.ndim == 2 else 0,
               _native.MODE_O if mode == "O" else _native.MODE_X)
@@ -63,7 +64,7 @@ def _trace_rays(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, p
     return res
 
 
-def _trace_fan(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, controls):
+def _trace_fan(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, controls, math=None):
     if mode not in ("O", "X"):
         raise ValueError("Mode must be O or X")
     f = np.ascontiguousarray(np.atleast_1d(np.asarray(f0_Hz, dtype=np.float64)))
@@ -91,6 +92,7 @@ def _trace_fan(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, re
     pz = np.empty((n_rays, stride), dtype=np.float64) if return_paths else None
     r_e, dz_t, boost, nsub = controls if spherical else (6371.0, 1.0, 200.0, 400)
     ctx = _native.host_context(device)
+    ctx.set_math(MATH_AUTO if math is None else int(math))
     rc = ctx.snell_fan(1 if spherical else 0, group_f.ctypes.data, group_p.ctypes.data, n_groups, ray_group.ctypes.data,
                        ray_e.ctypes.data, n_rays, d2.ctypes.data, b2.ctypes.data, p2.ctypes.data, a.ctypes.data, n_prof,
                        n_alt, n_alt if a.ndim == 2 else 0, _native.MODE_O if mode == "O" else _native.MODE_X,
@@ -105,21 +107,22 @@ def _trace_fan(spherical, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, re
     return res
 
 
-def trace_fan_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, return_paths=False, device=None):
+def trace_fan_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, return_paths=False, device=None,
+                               math=None):
     """Every elevation of ``elevation_deg`` ``(E,)`` for every frequency of ``f0_Hz`` ``(F,)`` (and every profile
     when ``Ne, Babs, bpsi`` are ``(P, N_alt)``), flat Earth.  Returns the dict of ``trace_rays_cartesian_snells``
     with arrays of shape ``(F, E)`` (or ``(P, F, E)``), bit for bit the values the per-ray call gives for the
     same rays; the level-by-level refractive index is evaluated once per (profile, frequency) instead of once
     per ray (``prhf_snell_fan_f64``)."""
-    return _trace_fan(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, None)
+    return _trace_fan(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, None, math)
 
 
 def trace_fan_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
-                               apex_boost=200.0, max_substeps=400, R_E=None, return_paths=False, device=None):
+                               apex_boost=200.0, max_substeps=400, R_E=None, return_paths=False, device=None, math=None):
     """The same over a spherical Earth, with the reference's apex-refinement controls (library.py:1470-1473)."""
     r_e = constants()[2] if R_E is None else float(R_E)
     return _trace_fan(True, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device,
-                      (r_e, dz_target_km, apex_boost, max_substeps))
+                      (r_e, dz_target_km, apex_boost, max_substeps), math)
 
 
 def _single(r, apex_keys):
@@ -134,7 +137,7 @@ def _single(r, apex_keys):
 
 
 def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, profile_index=None,
-                                return_paths=False, device=None):
+                                return_paths=False, device=None, math=None):
     """Trace ``R`` rays over a flat Earth; ``f0_Hz`` and ``elevation_deg`` broadcast to ``(R,)``.
 
     ``Ne, Babs, bpsi`` are ``(N_alt,)`` or ``(P, N_alt)`` with ``profile_index`` ``(R,)`` choosing the
@@ -142,28 +145,37 @@ def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mo
     the reference's ``group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km`` plus the
     turning point ``x_turn_km, z_turn_km`` and ``n_path``; NaN for rays that never turn.  With
     ``return_paths`` also ``x`` and ``z``: ``(R, 2 N_alt + 1)`` padded with NaN.
+
+    ``x_midpoint, z_midpoint``: the reference's search (library.py:1248-1252) lands on the path node before the apex
+    or - one rounding away, for one ray in three - on the apex; here always the node before the apex, its
+    exact-arithmetic answer (the apex itself is ``x_turn_km, z_turn_km``).
+
+    ``math``: None (default) evaluates the refractive index of a level in the reduced algebra where that cannot move a
+    result - far from reflection and from the ray's turning point - and in the reference's operation order elsewhere
+    (within 1e-10 of ``library.MATH_FAITHFUL``, which keeps the reference's order at every level and agrees with
+    reference-run rays to 1e-12; about three times the time).  Fans always read faithful level tables.
     """
     return _trace_rays(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths,
-                       device)
+                       device, math=math)
 
 
 def trace_rays_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
                                 apex_boost=200.0, max_substeps=400, R_E=None, profile_index=None,
-                                return_paths=False, device=None):
+                                return_paths=False, device=None, math=None):
     """The same over a spherical Earth (Bouguer's law), with the reference's apex-refinement controls
     (library.py:1470-1473); ``x`` is the ground distance ``R_E * phi``."""
     r_e = constants()[2] if R_E is None else float(R_E)
     return _trace_rays(True, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths, device,
-                       controls=(r_e, dz_target_km, apex_boost, max_substeps))
+                       controls=(r_e, dz_target_km, apex_boost, max_substeps), math=math)
 
 
-def trace_ray_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, device=None):
+def trace_ray_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, *, device=None, math=None):
     """One ray; the reference's signature and result dict (library.py:1096-1268):
     ``x, z`` (path arrays), ``group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km,
     x_apex_km, z_apex_km`` (the apex entries repeat the midpoint, as in the reference).  A ray that
     never turns returns NaN for every entry."""
     r = trace_rays_cartesian_snells(np.float64(f0_Hz), np.float64(elevation_deg), alt_km, Ne, Babs, bpsi, mode,
-                                    return_paths=True, device=device)
+                                    return_paths=True, device=device, math=math)
     return _single(r, apex_keys=True)
 
 
@@ -173,7 +185,7 @@ def trace_ray_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mod
     A ray that never turns returns the reference's seven-key NaN dict (library.py:1577-1583)."""
     r = trace_rays_spherical_snells(np.float64(f0_Hz), np.float64(elevation_deg), alt_km, Ne, Babs, bpsi, mode,
                                     dz_target_km=dz_target_km, apex_boost=apex_boost, max_substeps=max_substeps,
-                                    R_E=R_E, return_paths=True, device=device)
+                                    R_E=R_E, return_paths=True, device=device, math=math)
     return _single(r, apex_keys=False)
 
 
