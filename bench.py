@@ -346,7 +346,7 @@ def f_row_legs(torch, dev, ctx, library, synth):
     F, N = 1024, 20000
     fhz = torch.as_tensor(np.linspace(0.5, 16.0, F) * 1e6, device=dev)
     tt = [torch.as_tensor(x, device=dev) for x in (d1[0], b1[0], p1[0], a1)]
-    mult = torch.as_tensor(library._multiplier(N), device=dev)
+    mult = torch.as_tensor(np.array(library._multiplier(N)), device=dev)
     outs = [torch.empty(F, N, dtype=torch.float64, device=dev) for _ in range(7)] + [torch.empty(F, N, dtype=torch.int64, device=dev)]
     ptrs = [o.data_ptr() for o in outs]
     ms = best(lambda: ctx.regrid(fhz.data_ptr(), F, tt[0].data_ptr(), tt[1].data_ptr(), tt[2].data_ptr(), tt[3].data_ptr(),
@@ -418,7 +418,9 @@ def host_buffer_leg(library, freq, alt, den, bmag, bpsi, mode, n_points, math, k
     return {"integrals_per_s": n_prof * n_freq / dt, "ms_per_call": 1e3 * dt, "h2d_bytes": bytes_in, "d2h_bytes": bytes_out,
             "effective_h2d_gbs": bytes_in / dt / 1e9, "kernel_ms_resident": kernel_ms,
             "ratio_to_resident_kernel": (1e3 * dt / kernel_ms) if kernel_ms else None,
-            "note": "PCIe-inclusive (pageable host memory in and out); never `value`; effective_h2d_gbs = input bytes / whole call"}
+            "note": "PCIe-inclusive (pageable host memory in and out); never `value`; effective_h2d_gbs = input bytes / the whole "
+                    "call (upload, kernel and download overlap in slabs: where the kernel dominates - config 4 - it says nothing "
+                    "about the link)"}
 
 
 def arm_watchdog(seconds, what, rank):

@@ -770,7 +770,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 HIP_TRY(prhf::launch_short_order(as, order, short_stream));
                 as.order = order;
             }
-            HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, short_stream));
+            HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, (kn.short_lanes < 12 ? 8 : 16), short_stream));
             if (second) {
                 // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
                 // the device (3 us when there is none); what these leave - another input shape - joins the general list
@@ -784,7 +784,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 a2.queue = c->d_status + 0;
                 const size_t lds2 = prhf::short_lds_fixed(lds_levels, n_freq, PRHF_SHORT_THREADS) + 8 * (size_t)short_queue;
                 const long long slots2 = (long long)c->cu_count * (lds2 <= lds_half ? 2 : 1);
-                HIP_TRY(prhf::launch_vfo_short(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, short_stream));
+                HIP_TRY(prhf::launch_vfo_short(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, (kn.short_lanes < 12 ? 8 : 16), short_stream));
             }
         }
 #ifdef PRHF_TRACE

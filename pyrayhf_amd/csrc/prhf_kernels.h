@@ -191,7 +191,7 @@ hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_a
                               unsigned* max_peak, hipStream_t stream);
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue; threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
-hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream);
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, int lanes, hipStream_t stream);
 // the blocks of the short-grid launch `a` sorted into cost classes: order[0 .. CLASSES) counts (zeroed by the caller),
 // then CLASSES lists of a.n_blocks entries
 hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream);

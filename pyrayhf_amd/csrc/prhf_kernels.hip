@@ -2515,17 +2515,23 @@ hipError_t launch_residual(const double* vh_model, const double* vh_obs, long lo
 
 #include "prhf_short.inc"
 
-hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream) {
-    if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
+static const void* short_kernel_for(int threads, int lanes) {
     if (threads == PRHF_COMPACT_THREADS)
-        hipLaunchKernelGGL((vfo_short_kernel<PRHF_COMPACT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_COMPACT_THREADS),
-                           lds_bytes, stream, a);
-    else if (threads == PRHF_SHORT_THREADS)
-        hipLaunchKernelGGL((vfo_short_kernel<PRHF_SHORT_THREADS>), dim3((unsigned)grid_blocks), dim3(PRHF_SHORT_THREADS),
-                           lds_bytes, stream, a);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
+        return lanes == 8 ? reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_COMPACT_THREADS, 8>)
+                          : reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_COMPACT_THREADS, 16>);
+    if (threads == PRHF_SHORT_THREADS)
+        return lanes == 8 ? reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS, 8>)
+                          : reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS, 16>);
+    return nullptr;
+}
+
+// lanes: 16 or 8 lanes per pair (vfo_short_kernel's LP)
+hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, int lanes, hipStream_t stream) {
+    if (grid_blocks <= 0 || a.n_blocks <= 0) return hipSuccess;
+    const void* kernel = short_kernel_for(threads, lanes);
+    if (!kernel || (lanes != 8 && lanes != 16)) return hipErrorInvalidValue;
+    void* params[] = {const_cast<KArgs*>(&a)};
+    return hipLaunchKernel(kernel, dim3((unsigned)grid_blocks), dim3((unsigned)threads), params, lds_bytes, stream);
 }
 
 hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream) {
@@ -2564,8 +2570,8 @@ hipError_t configure_kernels(size_t max_lds_bytes) {
     const void* kernels[] = {reinterpret_cast<const void*>(&vfo_kernel<0, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<1, THREADS>),
                              reinterpret_cast<const void*>(&vfo_kernel<2, THREADS>),
-                             reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_SHORT_THREADS>),
-                             reinterpret_cast<const void*>(&vfo_short_kernel<PRHF_COMPACT_THREADS>),
+                             short_kernel_for(PRHF_SHORT_THREADS, 16), short_kernel_for(PRHF_SHORT_THREADS, 8),
+                             short_kernel_for(PRHF_COMPACT_THREADS, 16), short_kernel_for(PRHF_COMPACT_THREADS, 8),
                              reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_SHORT_THREADS>),
                              reinterpret_cast<const void*>(&vfo_shortx_kernel<PRHF_COMPACT_THREADS>),
                              reinterpret_cast<const void*>(&regrid_kernel<512>)};

@@ -50,6 +50,8 @@ struct Knobs {
                                        // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3)
     double short_order = 1;            // long short-grid O launches draw their blocks in descending order of a cost estimate
                                        // (a pre-pass over sixteen samples of every density column; 0: index order)
+    double short_lanes = 8;            // short-grid O kernel: lanes per pair, 16 (four pairs per work item) or 8 (eight: half the
+                                       // items and their set-up per profile, no half-empty last wave-iteration on 200 points)
     double host_slabs = 3;             // large host-buffer batches are uploaded, evaluated and returned in this many slabs of
                                        // profiles (10 % / 30 % / 60 %) so that the transfers of one overlap the kernel of
                                        // another (1: one upload, one launch, one download)
@@ -91,6 +93,7 @@ const KnobName kKnobNames[] = {
     {"short_prio", &Knobs::short_prio, 0, 3},
     {"host_slabs", &Knobs::host_slabs, 1, 3},
     {"short_order", &Knobs::short_order, 0, 1},
+    {"short_lanes", &Knobs::short_lanes, 8, 16},
     {"snell_table", &Knobs::snell_table, 0, 1e9},
     {"tall_lean", &Knobs::tall_lean, 0, 1},
 };

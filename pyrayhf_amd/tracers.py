@@ -180,7 +180,7 @@ def trace_ray_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mod
 
 
 def trace_ray_spherical_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode="O", *, dz_target_km=1.0,
-                               apex_boost=200.0, max_substeps=400, R_E=None, device=None):
+                               apex_boost=200.0, max_substeps=400, R_E=None, device=None, math=None):
     """One ray over a spherical Earth; the reference's signature and result dict (library.py:1460-1713).
     A ray that never turns returns the reference's seven-key NaN dict (library.py:1577-1583)."""
     r = trace_rays_spherical_snells(np.float64(f0_Hz), np.float64(elevation_deg), alt_km, Ne, Babs, bpsi, mode,

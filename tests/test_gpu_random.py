@@ -305,16 +305,26 @@ def test_compact_short_grid_geometry_changes_nothing(seed):
             if P * F < 4096 or np.any(np.argmax(den, axis=1) == 0):
                 continue
             n = int(rng.choice([64, 200, 333, 1024]))
-            outs = {}
-            for compact in (0, 1):
-                library.set_option("short_compact", compact)
-                for q in (0, 24):
-                    library.set_option("short_queue", q)
-                    outs[(compact, q)] = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", n)
-            base = outs[(0, 0)]
-            assert np.isfinite(base).any()
-            for key, got in outs.items():
-                assert np.array_equal(got, base, equal_nan=True), (seed, n_alt, F, n, key)
+            # ... and so with sixteen and with eight lanes per pair (round 5, option short_lanes: another order of
+            # additions in a pair's sum, so the two agree to rounding - 1e-13 - and each is bit-stable across geometries)
+            bases = []
+            for lanes in (8, 16):
+                library.set_option("short_lanes", lanes)
+                outs = {}
+                for compact in (0, 1):
+                    library.set_option("short_compact", compact)
+                    for q in (0, 24):
+                        library.set_option("short_queue", q)
+                        outs[(compact, q)] = library.vertical_forward_operator(freq, den, bmag, bpsi, alt, "O", n)
+                base = outs[(0, 0)]
+                assert np.isfinite(base).any()
+                for key, got in outs.items():
+                    assert np.array_equal(got, base, equal_nan=True), (seed, n_alt, F, n, lanes, key)
+                bases.append(base)
+            assert np.array_equal(np.isnan(bases[0]), np.isnan(bases[1]))
+            ok = np.isfinite(bases[0])
+            assert np.max(np.abs(bases[0][ok] - bases[1][ok]) / np.abs(bases[0][ok])) <= 1e-12, (seed, n_alt, F, n)
+            library.set_option("short_lanes", 8)
             # the X-mode short-grid kernel has the same two geometries (second session of round 4): a profile that
             # peaks above the compact arrays takes a second launch of the same kernel with full-size arrays
             library.set_option("short_queue", 0)
@@ -327,3 +337,4 @@ def test_compact_short_grid_geometry_changes_nothing(seed):
     finally:
         library.set_option("short_compact", 1)
         library.set_option("short_queue", 0)
+        library.set_option("short_lanes", 8)
