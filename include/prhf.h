@@ -120,6 +120,11 @@ int prhf_ctx_set_math(prhf_ctx* ctx, int level);
  *                        bottomside of the launch fits LDS, only the levels up to the highest peak are staged)
  *   "tall_lean"          0: a profile staged in global memory takes the generic loop (1: the main loop reads its nodes
  *                        from the slab)
+ *   "short_compact", "short_prio", "short_order", "short_lanes"
+ *                        geometry of the short-grid kernels: four 4-wave workgroups per CU (1), wave priorities by age (1),
+ *                        blocks in descending cost order (1), lanes per pair in the O kernel (8; 16: four pairs per work
+ *                        item instead of eight - another order of additions in a pair's sum, 1e-16 apart)
+ *   "host_slabs"         large host-buffer batches go in this many slabs so that transfers overlap the kernel (3; 1: none)
  *   "snell_table"        tracers: the frequency-independent parts of a level's mu, mu' (f_N^2, g_p |B|, sin psi, cos psi)
  *                        are tabulated once per profile when the rays (groups) number at least this many times the
  *                        profiles and the table stays under 1 GiB (4; 0: never) */
@@ -238,7 +243,11 @@ int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
  * (n_prof, n_alt) columns; a ground level at z = 0 is inserted when alt[0] > 0, as in the reference.
  * out is (n_rays, 8): group_path_km, group_delay_sec, x_midpoint, z_midpoint, ground_range_km (the
  * reference's dict entries; its x_apex_km / z_apex_km equal the midpoint), then x and z of the turning
- * point and the number of path nodes.  Rays that never turn give NaN (node count 0).  path_x / path_z
+ * point and the number of path nodes.  The midpoint is the path node before the apex: the exact-arithmetic answer of
+ * the reference's search (library.py:1248-1252), whose own rounding lands there for two rays in three and on the apex
+ * for the third.  Arithmetic (prhf_ctx_set_math): PRHF_MATH_FAITHFUL evaluates mu and mu' of every level in the
+ * reference's operation order (reference-run rays to 1e-12); the default evaluates levels far from reflection and from
+ * the ray's turning point in the reduced algebra (within 1e-10 of the former).  Rays that never turn give NaN (node count 0).  path_x / path_z
  * (optional, (n_rays, path_stride), path_stride >= 2 n_alt + 1) receive the reference's 'x' and 'z'
  * arrays padded with NaN.  Synchronous; PRHF_ENEGDEN on a negative density; PRHF_EINVAL when a
  * profile_index lies outside [0, n_prof) - checked on the host for host buffers and by the kernel for

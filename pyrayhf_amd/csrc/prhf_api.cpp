@@ -750,6 +750,10 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(as.leftover_tall, 0, sizeof(unsigned), short_stream));
             }
             const int threads = compact ? PRHF_COMPACT_THREADS : PRHF_SHORT_THREADS;
+            // lanes per pair: eight on grids of up to 256 points (the launch's longest), sixteen beyond (Knobs::short_lanes)
+            int longest = 0;
+            for (int i = 0; i < n_kind; ++i) longest = std::max(longest, kind_seg[i].n_points);
+            const int short_lanes = kn.short_lanes == 0 ? (longest <= 256 ? 8 : 16) : (kn.short_lanes < 12 ? 8 : 16);
             const int queue_entries = compact ? compact_queue : short_queue;
             as.lds_levels = compact ? compact_levels : lds_levels;
             as.short_queue = fixed_q ? fixed_q : queue_entries;
@@ -770,7 +774,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 HIP_TRY(prhf::launch_short_order(as, order, short_stream));
                 as.order = order;
             }
-            HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, (kn.short_lanes < 12 ? 8 : 16), short_stream));
+            HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, short_lanes, short_stream));
             if (second) {
                 // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
                 // the device (3 us when there is none); what these leave - another input shape - joins the general list
@@ -784,7 +788,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 a2.queue = c->d_status + 0;
                 const size_t lds2 = prhf::short_lds_fixed(lds_levels, n_freq, PRHF_SHORT_THREADS) + 8 * (size_t)short_queue;
                 const long long slots2 = (long long)c->cu_count * (lds2 <= lds_half ? 2 : 1);
-                HIP_TRY(prhf::launch_vfo_short(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, (kn.short_lanes < 12 ? 8 : 16), short_stream));
+                HIP_TRY(prhf::launch_vfo_short(a2, std::min(short_blocks, slots2), lds2, PRHF_SHORT_THREADS, short_lanes, short_stream));
             }
         }
 #ifdef PRHF_TRACE

@@ -35,6 +35,8 @@
 #define PRHF_SHORT_MAX_POINTS 1024  // (16 wave-iterations: one violation mask each, per wave)
 #define PRHF_SHORTX_MAX_POINTS 1024  // X mode (fast tier) up to this many points: vfo_shortx_kernel (no top-segment phase;
                                     // measured against the general kernel: -38 % at 200 points, -21 % at 500, -7 % at 1000, +6 % at 2000)
+#define PRHF_SHORT_MASKS 32         // violation masks a wave keeps per work item: wave-iterations of the item that hold
+                                    // ill-conditioned points (more: every point of the item's pairs in the reference's order)
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
 #define PRHF_ORDER_CLASSES 16       // cost classes of the short-grid launch's block order (short_order_kernel)
 #define PRHF_COMPACT_THREADS 256    // the compact geometry of the short-grid O kernel: four 4-wave workgroups per CU, staged
@@ -141,7 +143,7 @@ inline size_t tall_slab_bytes(long long n_alt) {
 // LDS of one short-grid workgroup (vfo_short_kernel): the per-frequency lists and scratch in front, then n_alt + 1
 // nodes, then `queue` entries of 8 bytes (a profile with K < n_alt levels adds its unused nodes to the queue).
 inline __host__ __device__ size_t short_lds_lists(long long n_alt, long long n_freq, int threads) {
-    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(threads / 64) * 16 * 12 +
+    const size_t b = (size_t)(n_alt > n_freq ? n_alt : n_freq) * 8 + (size_t)n_freq * 24 + (size_t)(threads / 64) * PRHF_SHORT_MASKS * 12 +
                      PRHF_RED_DOUBLES * 8 + (size_t)n_freq * 4 + (size_t)n_freq * 2;
     return (b + 15) & ~(size_t)15;
 }

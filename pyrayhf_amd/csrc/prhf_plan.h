@@ -45,13 +45,20 @@ struct Knobs {
     double short_compact = 1;          // short O-mode grids: four 4-wave workgroups per CU whose staged arrays hold as many
                                        // levels as a quarter of the LDS allows; a profile whose peak lies higher goes to a
                                        // second launch with full-size arrays (0: two 8-wave workgroups per CU only)
-    double short_prio = 1;             // short-grid O kernel: wave priority of a block's items by age (1: the blocks of the last
+    double short_prio = 4;             // short-grid O kernel, bits: wave priority of a block's items by age (1: the blocks of the last
                                        // three resident rounds rank below everything pulled before them - config 3 -2.7 %),
-                                       // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3)
+                                       // by cost (2: a profile with many reflecting frequencies outranks its neighbours), both (3);
+                                       // by phase (4, the default since round 5: staging, lists, the queue and the final sums -
+                                       // latency chains of few instructions - run above every main loop of the CU, whose other
+                                       // workgroups' loops fill the issue slots: config 3 -1.5 %, the O/200 slice of config 5
+                                       // -1.8 % against 1; with the age rule on top, 5: -1.9 % / +1.4 %)
     double short_order = 1;            // long short-grid O launches draw their blocks in descending order of a cost estimate
                                        // (a pre-pass over sixteen samples of every density column; 0: index order)
-    double short_lanes = 8;            // short-grid O kernel: lanes per pair, 16 (four pairs per work item) or 8 (eight: half the
-                                       // items and their set-up per profile, no half-empty last wave-iteration on 200 points)
+    double short_lanes = 0;            // short-grid O kernel: lanes per pair, 16 (four pairs per work item) or 8 (eight: half the
+                                       // items and their set-up per profile, no half-empty last wave-iteration on 200 points;
+                                       // but eight pairs' nodes per LDS read: more bank conflicts).  0: eight on grids of up
+                                       // to 256 points, sixteen beyond (measured: -12 % at 50 points, -4 % at 200, -1 % at 256,
+                                       // +1 % at 400, +22 % at 1000)
     double host_slabs = 3;             // large host-buffer batches are uploaded, evaluated and returned in this many slabs of
                                        // profiles (10 % / 30 % / 60 %) so that the transfers of one overlap the kernel of
                                        // another (1: one upload, one launch, one download)
@@ -90,10 +97,10 @@ const KnobName kKnobNames[] = {
     {"timing", &Knobs::timing, 0, 1},
     {"trim_lds", &Knobs::trim_lds, 0, 1},
     {"short_compact", &Knobs::short_compact, 0, 1},
-    {"short_prio", &Knobs::short_prio, 0, 3},
+    {"short_prio", &Knobs::short_prio, 0, 7},
     {"host_slabs", &Knobs::host_slabs, 1, 3},
     {"short_order", &Knobs::short_order, 0, 1},
-    {"short_lanes", &Knobs::short_lanes, 8, 16},
+    {"short_lanes", &Knobs::short_lanes, 0, 16},
     {"snell_table", &Knobs::snell_table, 0, 1e9},
     {"tall_lean", &Knobs::tall_lean, 0, 1},
 };

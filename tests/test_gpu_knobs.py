@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     "short_queue=24",
     "local_chunks=0,direct_upload=0,timing=1",          # round 3: chunk sums through scratch + a second kernel, staged upload
     "trim_lds=0,shortx_kernel=0,tall_lean=0",           # profiles staged in global memory through the generic loop
-    "short_lanes=16,short_order=0,short_prio=0",        # round 5: sixteen lanes per pair (the default is eight), index order
+    "short_lanes=16,short_order=0,short_prio=1",        # round 5: sixteen lanes per pair at every grid size, index order, priorities by age
 ])
 def test_parity_subset_under_knobs(knobs):
     env = dict(os.environ, PRHF_TEST_OPTIONS=knobs)
