@@ -152,6 +152,8 @@ struct prhf_ctx {
     static constexpr int kHostGrids = 16;
     HostGrid host_grid[kHostGrids];
     int n_host_grids = 0;
+    bool order_clean = false;       // the class counters at the head of `order` are zero (short_order_kernel needs them so; the
+                                    // follow-up kernel of the launch that used them leaves them so)
     unsigned* d_status = nullptr;   // device words [1..5]: block queues of persistent launches (general, short-grid O and its
                                     // follow-up, short-grid X and its follow-up); [6]: ray queue of the per-ray tracer launch;
                                     // [0] unused
@@ -559,6 +561,15 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
     const bool timed_launch = dev || kn.timing != 0;
     if (timed_launch) HIP_TRY(hipEventRecord(c->begin_ev(), c->stream));
     bool zeroed_by_table = false;              // the control words below were zeroed by the per-frequency table's kernel
+    unsigned* order_made = nullptr;            // ... which also sorted the short-grid O launch's blocks by cost (short_order_kernel)
+    // resident workgroups of the short-grid O launch (launch_short_kind sizes it the same way)
+    auto short_o_slots = [&]() -> long long {
+        const bool compact = compact_levels > 0;
+        const int threads = compact ? PRHF_COMPACT_THREADS : PRHF_SHORT_THREADS;
+        const size_t lds = prhf::short_lds_fixed(compact ? compact_levels : lds_levels, n_freq, threads) +
+                           8 * (size_t)(compact ? compact_queue : short_queue);
+        return (long long)c->cu_count * (compact ? PRHF_COMPACT_WGS_PER_CU : (lds <= lds_half ? 2 : 1));
+    };
     if (want_pairs && grid) {
         if (!grid->pairs_ready) {
             if ((rc = ensure(c, grid->pairs, ((size_t)mult_len + PRHF_PAIR_PAD) * 16)) != PRHF_OK) return rc;
@@ -600,19 +611,40 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
             };
             zero.p[zero.n] = c->d_status;
             zero.words[zero.n++] = kStatusWords;
+            long long o_blocks = 0;
             for (int xmode = 0; xmode < 2; ++xmode) {
                 long long kind_blocks = 0;
                 for (int i = 0; i < (xmode ? n_shortx : n_short); ++i)
                     kind_blocks += (xmode ? shortx_seg : short_seg)[i].prof_end - (xmode ? shortx_seg : short_seg)[i].prof_begin;
                 if (kind_blocks == 0 || kind_blocks > 0x7fffffffLL) continue;
+                if (!xmode) o_blocks = kind_blocks;
                 const size_t list_bytes = (size_t)(kind_blocks + 1) * sizeof(unsigned);
                 if ((rc = zero_head(xmode ? c->leftover_x : c->leftover, list_bytes, 1)) != PRHF_OK) return rc;
                 if ((rc = zero_head(xmode ? c->leftover_tall_x : c->leftover_tall, list_bytes, 1)) != PRHF_OK) return rc;
-                if (!xmode && kn.short_order != 0 &&
-                    (rc = zero_head(c->order, PRHF_ORDER_CLASSES * (size_t)(kind_blocks + 1) * sizeof(unsigned), PRHF_ORDER_CLASSES)) != PRHF_OK)
-                    return rc;
             }
-            HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), zero, c->stream));
+            // A short-grid O launch of four resident rounds and more draws its blocks in descending order of a cost
+            // estimate: the kernel that sorts them makes the table as well (short_order_kernel)
+            if (o_blocks > 0 && kn.short_order != 0 && o_blocks >= 4 * short_o_slots()) {
+                const size_t words = PRHF_ORDER_CLASSES * (size_t)(o_blocks + 1);
+                const void* before = c->order.p;
+                if ((rc = ensure(c, c->order, words * sizeof(unsigned))) != PRHF_OK) return rc;
+                unsigned* order = static_cast<unsigned*>(c->order.p);
+                if (!c->order_clean || c->order.p != before)
+                    HIP_TRY(hipMemsetAsync(order, 0, PRHF_ORDER_CLASSES * sizeof(unsigned), c->stream));
+                prhf::KArgs ap = a;
+                ap.n_segs = n_short;
+                ap.n_blocks = 0;
+                for (int i = 0; i < n_short; ++i) {
+                    ap.seg[i] = short_seg[i];
+                    ap.seg[i].block_begin = ap.n_blocks;
+                    ap.n_blocks += short_seg[i].prof_end - short_seg[i].prof_begin;
+                }
+                c->order_clean = false;                // (until the follow-up kernel of this launch has run)
+                HIP_TRY(prhf::launch_short_order(ap, order, a.freq, static_cast<double*>(c->ftab.p), zero, c->stream));
+                order_made = order;
+            } else {
+                HIP_TRY(prhf::launch_freq_table(a.freq, n_freq, static_cast<double*>(c->ftab.p), zero, c->stream));
+            }
             a.ftab = static_cast<const double*>(c->ftab.p);
             zeroed_by_table = true;
         }
@@ -765,15 +797,7 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
                 grid_short = short_slots;
             }
             // from four resident rounds on, the blocks are drawn in descending order of a cost estimate
-            as.order = nullptr;
-            if (kn.short_order != 0 && short_blocks >= 4 * short_slots && as.ftab) {
-                const size_t words = PRHF_ORDER_CLASSES * (size_t)(short_blocks + 1);
-                if ((rcl = ensure(c, c->order, words * sizeof(unsigned))) != PRHF_OK) return rcl;
-                unsigned* order = static_cast<unsigned*>(c->order.p);
-                if (!zeroed_by_table) HIP_TRY(hipMemsetAsync(order, 0, PRHF_ORDER_CLASSES * sizeof(unsigned), short_stream));
-                HIP_TRY(prhf::launch_short_order(as, order, short_stream));
-                as.order = order;
-            }
+            as.order = order_made;             // (sorted beside the per-frequency table, or null: index order)
             HIP_TRY(prhf::launch_vfo_short(as, grid_short, lds, threads, short_lanes, short_stream));
             if (second) {
                 // the profiles the compact launch left for full-size arrays: persistent workgroups read their number from
@@ -810,7 +834,9 @@ int run(prhf_ctx* c, const double* freq, int64_t n_freq, const double* den, cons
         af.block_list = as.leftover;
         af.leftover = nullptr;
         af.queue = c->d_status + (xmode ? 5 : 3);
+        af.zero_after = (!xmode && order_made) ? order_made : nullptr;
         HIP_TRY(prhf::launch_vfo(af, std::min(short_blocks, wg_slots), xmode ? 1 : 0, prhf::lds_bytes_for(lds_levels), short_stream));
+        if (af.zero_after) c->order_clean = true;
         return PRHF_OK;
     };
     if ((rc = launch_short_kind(true)) != PRHF_OK) return rc;          // (the longer blocks first)

@@ -117,6 +117,7 @@ struct KArgs {
     int short_queue;                 // entries of the short-grid kernel's LDS queue
     int short_prio;                  // wave priorities of the short-grid O kernel's blocks (vfo_short_kernel)
     const unsigned* order;           // short-grid O launch: its blocks by cost class (short_order_kernel), or null: index order
+    unsigned* zero_after;            // general kernel, follow-up of such a launch: the class counters to leave at zero (or null)
     // Profiles taller than LDS holds (vfo_tall_kernel): one slab of tall_stride bytes per workgroup of the launch
     unsigned char* tall;
     unsigned long long tall_stride;
@@ -194,9 +195,11 @@ hipError_t launch_peak_levels(const double* den, long long n_prof, long long n_a
 // the short-grid kernel over a.n_blocks one-profile blocks (a.queue set: `grid_blocks` persistent workgroups);
 // lds_bytes = short_lds_fixed + 8 a.short_queue; threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
 hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, int lanes, hipStream_t stream);
-// the blocks of the short-grid launch `a` sorted into cost classes: order[0 .. CLASSES) counts (zeroed by the caller),
-// then CLASSES lists of a.n_blocks entries
-hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream);
+// the blocks of the short-grid launch `a` sorted into cost classes: order[0 .. CLASSES) counts (zero when the launch
+// starts), then CLASSES lists of a.n_blocks entries; the same launch makes the per-frequency table `tab` of
+// launch_freq_table and zeroes `zero`'s control words
+hipError_t launch_short_order(const KArgs& a, unsigned* order, const double* freq_mhz, double* tab, const ZeroWords& zero,
+                              hipStream_t stream);
 // the X-mode variant; lds_bytes = shortx_lds_bytes(a.lds_levels, n_freq); threads: PRHF_SHORT_THREADS or PRHF_COMPACT_THREADS
 hipError_t launch_vfo_shortx(const KArgs& a, long long grid_blocks, size_t lds_bytes, int threads, hipStream_t stream);
 // absmax_scratch: 2 x u64 device words, absmax_host: 2 x u64 pinned host words

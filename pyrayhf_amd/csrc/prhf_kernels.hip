@@ -1947,6 +1947,9 @@ __device__ __forceinline__ void vfo_kernel_body(const KArgs& a) {
     // Follow-up of a short-grid launch: the blocks to evaluate are listed (block_list[1 .. block_list[0]])
     const unsigned* list = a.block_list;
     const long long n_blocks = list ? (long long)list[0] : a.n_blocks;
+    // (the last kernel behind a short-grid launch whose blocks were drawn in cost order leaves the class counters at
+    //  zero for the next call's short_order_kernel)
+    if (a.zero_after && blockIdx.x == 0 && threadIdx.x < PRHF_ORDER_CLASSES) a.zero_after[threadIdx.x] = 0u;
     long long ticket = blockIdx.x;
     if (ticket >= n_blocks) return;
     long long bid = list ? (long long)list[1 + ticket] : ticket;
@@ -2534,9 +2537,11 @@ hipError_t launch_vfo_short(const KArgs& a, long long grid_blocks, size_t lds_by
     return hipLaunchKernel(kernel, dim3((unsigned)grid_blocks), dim3((unsigned)threads), params, lds_bytes, stream);
 }
 
-hipError_t launch_short_order(const KArgs& a, unsigned* order, hipStream_t stream) {
-    if (a.n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(short_order_kernel, dim3((unsigned)((a.n_blocks + 63) / 64)), dim3(1024), 0, stream, a, order);
+hipError_t launch_short_order(const KArgs& a, unsigned* order, const double* freq_mhz, double* tab, const ZeroWords& zero,
+                              hipStream_t stream) {
+    if (a.n_blocks <= 0) return hipErrorInvalidValue;        // (the table must be made: the caller takes launch_freq_table then)
+    hipLaunchKernelGGL(short_order_kernel, dim3((unsigned)((a.n_blocks + 63) / 64)), dim3(1024), 0, stream, a, order, freq_mhz,
+                       tab, zero);
     return hipGetLastError();
 }
 
