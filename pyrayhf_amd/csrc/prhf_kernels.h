@@ -39,7 +39,9 @@
                                     // ill-conditioned points (more: every point of the item's pairs in the reference's order)
 #define PRHF_SHORT_MAX_QUEUE 4096   // entries of the LDS queue of ill-conditioned points, at most
 #define PRHF_ORDER_CLASSES 16       // cost classes of the short-grid launch's block order (short_order_kernel)
+#ifndef PRHF_COMPACT_THREADS
 #define PRHF_COMPACT_THREADS 256    // the compact geometry of the short-grid O kernel: four 4-wave workgroups per CU, staged
+#endif
 #ifndef PRHF_COMPACT_WGS_PER_CU
 #define PRHF_COMPACT_WGS_PER_CU 4   // arrays for as many levels as a quarter of the LDS holds
 #endif
@@ -58,6 +60,13 @@
 #endif
 
 namespace prhf {
+
+// waves per SIMD the short-grid kernels' register budget is set for: the compact geometry keeps PRHF_COMPACT_WGS_PER_CU
+// workgroups of `threads` per CU resident (256 threads: 4 x 4 waves = 4 per SIMD; 320: 5), the full-size one two of 512
+constexpr int short_waves_per_simd(int threads) {
+    return threads < PRHF_SHORT_THREADS && threads * PRHF_COMPACT_WGS_PER_CU / 256 > PRHF_SHORT_WAVES_PER_SIMD
+               ? threads * PRHF_COMPACT_WGS_PER_CU / 256 : PRHF_SHORT_WAVES_PER_SIMD;
+}
 
 // One homogeneous slice of a launch, with its decomposition into blocks.
 struct SegDev {

@@ -111,8 +111,8 @@ def trace_fan_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mod
                                math=None):
     """Every elevation of ``elevation_deg`` ``(E,)`` for every frequency of ``f0_Hz`` ``(F,)`` (and every profile
     when ``Ne, Babs, bpsi`` are ``(P, N_alt)``), flat Earth.  Returns the dict of ``trace_rays_cartesian_snells``
-    with arrays of shape ``(F, E)`` (or ``(P, F, E)``), bit for bit the values the per-ray call gives for the
-    same rays; the level-by-level refractive index is evaluated once per (profile, frequency) instead of once
+    with arrays of shape ``(F, E)`` (or ``(P, F, E)``): the values the per-ray call gives for the same rays in the
+    reference's operation order (``math=library.MATH_FAITHFUL``), to 1e-13; the level-by-level refractive index is evaluated once per (profile, frequency) instead of once
     per ray (``prhf_snell_fan_f64``)."""
     return _trace_fan(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, return_paths, device, None, math)
 

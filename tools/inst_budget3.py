@@ -14,16 +14,20 @@ dev = torch.device("cuda", 0); ctx = _native.context(0)
 alt, den, bmag, bpsi = synth.chapman_profiles(10000, 20260003)
 t = [torch.as_tensor(x, device=dev) for x in (den, bmag, bpsi, alt)]
 f174 = synth.sounder_frequencies(3)
+def lanes_for(n):                      # the library's rule (Knobs::short_lanes = 0): eight lanes per pair up to 256 points
+    forced = OPTIONS.get("short_lanes", 0)
+    return int(forced) if forced else (8 if n <= 256 else 16)
+
+
+def iterations(n):
+    return -(-n // lanes_for(n))
+
+
 VARIANTS = [("one escaping frequency (staging, one list pass)", [30.0], 200, None),
-            ("174 escaping frequencies (staging + list)", np.full(174, 30.0), 200, None),
-            ("config 3 at n_points = 2 (one wave-iteration per item)", f174, 2, None),
-            ("n_points = 18 (two)", f174, 18, None),
-            ("n_points = 34 (three)", f174, 34, None),
-            ("n_points = 66 (five)", f174, 66, None),
-            ("n_points = 130 (nine)", f174, 130, None),
-            ("config 3: n_points = 200 (thirteen)", f174, 200, None),
-            ("config 3, no point queued (well_conditioned = 0)", f174, 200, 0.0),
-            ("n_points = 392 (twenty-five)", f174, 392, None)]
+            ("174 escaping frequencies (staging + list)", np.full(174, 30.0), 200, None)]
+for n in (2, 18, 34, 66, 130, 200, 256):
+    VARIANTS.append((f"{'config 3: ' if n == 200 else ''}n_points = {n} ({iterations(n)} wave-iterations per item, {lanes_for(n)} lanes per pair)", f174, n, None))
+VARIANTS.append(("config 3, no point queued (well_conditioned = 0)", f174, 200, 0.0))
 for name, freq, n, wc in VARIANTS:
     f = torch.as_tensor(np.asarray(freq, dtype=np.float64), device=dev)
     library.set_option("well_conditioned", 1e-5 if wc is None else wc)
@@ -33,5 +37,6 @@ for name, freq, n, wc in VARIANTS:
         ms.append(ctx.last_kernel_ms())
     torch.cuda.synchronize()
     print(json.dumps({"variant": name, "n_freq": int(f.numel()), "n_points": n, "well_conditioned": wc, "reps": REPS,
+                      "iterations": iterations(n), "lanes": lanes_for(n),
                       "kernel_ms": min(ms[1:]), "finite": float(torch.isfinite(out).double().mean()), "options": OPTIONS}), flush=True)
 library.set_option("well_conditioned", 1e-5)

@@ -61,37 +61,41 @@ def main():
         lines.append(f"| {r['variant']} | {ms:.4f} | {r.get('SQ_INSTS_VALU', float('nan')):.4g} | {r.get('SQ_INSTS_SALU', float('nan')):.4g} | "
                      f"{r.get('SQ_INSTS_LDS', float('nan')):.4g} | {r.get('SQ_INSTS_VALU_TRANS_F64', float('nan')):.4g} | {busy:.3f} | {occ:.2f} |")
     lines.append("")
-    by = {r["variant"].split(" (")[0].split(":")[0]: r for r in rows}
     def get(prefix):
         for r in rows:
             if r["variant"].startswith(prefix):
                 return r
         return None
-    one, esc, n2, n18, n34, n66, n130, full, noq, n392 = (get(p) for p in (
-        "one escaping", "174 escaping", "config 3 at n_points = 2", "n_points = 18", "n_points = 34", "n_points = 66",
-        "n_points = 130", "config 3: n_points = 200", "config 3, no point queued", "n_points = 392"))
-    if all(x is not None and "SQ_INSTS_VALU" in x for x in (one, esc, n2, n18, n34, n66, n130, full, noq, n392)):
+    one, esc, noq = get("one escaping"), get("174 escaping"), get("config 3, no point queued")
+    grids = [r for r in rows if "wave-iterations per item" in r["variant"]]
+    full = next((r for r in grids if r["n_points"] == 200), None)
+    if one and esc and noq and full and len(grids) >= 3 and all("SQ_INSTS_VALU" in r for r in grids + [one, esc, noq]):
         P = 10000.0
         v = lambda r: r["SQ_INSTS_VALU"] / P
-        per_iter = (v(n392) - v(full)) / 12.0
-        items = None
-        lines += ["## Split of config 3's VALU instructions (per profile, wave instructions)", "",
-                  f"* a wave-iteration of the checked main loop, all items of a profile together: (n = 392 minus n = 200) / 12 = "
-                  f"**{per_iter:.0f}** per profile and wave-iteration",
-                  f"* staging (argmax, nodes, running maximum) + one pass of the list: **{v(one):.0f}**",
-                  f"* the candidate list over 174 frequencies: + **{v(esc) - v(one):.0f}**",
-                  f"* items at n_points = 2 - per-item set-up, the last wave-iteration, reductions, queue bookkeeping, the queue's "
-                  f"entries (one per pair: the point at the reflection height), the final sums: + **{v(n2) - v(esc):.0f}**",
-                  f"* the 12 wave-iterations in front of the last one at n_points = 200: **{v(full) - v(n2):.0f}** "
-                  f"(of which what the queue adds over n_points = 2: {v(full) - v(noq):.0f} = default minus `well_conditioned = 0`, "
-                  f"which queues nothing at all)",
-                  f"* total **{v(full):.0f}** per profile = {full['SQ_INSTS_VALU']:.4g} per launch", ""]
         t = lambda r: r.get("trace_ms", r["kernel_ms"])
-        lines += ["## The same split in time (ms per launch; phases overlap across the four workgroups of a CU, so the differences are "
-                  "what a phase ADDS to the launch, not what it would take alone)", "",
-                  f"* staging + one list pass {t(one):.3f}; + list over 174 frequencies {t(esc) - t(one):+.3f}; + items at n_points = 2 "
-                  f"{t(n2) - t(esc):+.3f}; + the loop up to n_points = 200 {t(full) - t(n2):+.3f} (no queue: {t(noq):.3f}); "
-                  f"per wave-iteration beyond 200 points {(t(n392) - t(full)) / 12 * 1e3:.1f} us", ""]
+        # least squares over the grid sizes with the same lane count as config 3: instructions = fixed + slope x wave-iterations
+        same = [r for r in grids if r.get("lanes") == full.get("lanes")]
+        xs = [float(r["iterations"]) for r in same]
+        n = len(xs)
+
+        def fit(ys):
+            mx, my = sum(xs) / n, sum(ys) / n
+            slope = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+            return slope, my - slope * mx
+        slope, fixed = fit([v(r) for r in same])
+        tslope, tfixed = fit([t(r) for r in same])
+        it = full["iterations"]
+        lines += [f"## Split of config 3's VALU instructions (per profile, wave instructions; {full.get('lanes')} lanes per pair, {it} wave-iterations per item)", "",
+                  f"* straight line through the grid sizes {', '.join(str(r['n_points']) for r in same)}: **{slope:.0f}** per profile and wave-iteration "
+                  f"(all items of a profile together) + **{fixed:.0f}** that do not depend on the grid",
+                  f"* of the fixed part: staging (argmax, nodes, running maximum) + one pass of the list **{v(one):.0f}**; the candidate list "
+                  f"over 174 frequencies + **{v(esc) - v(one):.0f}**; per-item set-up, reductions, the queue's bookkeeping and its entries "
+                  f"(at least one per pair: the point at the reflection height), the final sums **{fixed - v(esc):.0f}**",
+                  f"* config 3: {it} x {slope:.0f} = **{it * slope:.0f}** in the loop of **{v(full):.0f}** in all ({full['SQ_INSTS_VALU']:.4g} per launch); "
+                  f"what the ill-conditioned points cost (default minus `well_conditioned = 0`, which queues nothing): **{v(full) - v(noq):.0f}**", "",
+                  "## The same split in time (ms per launch; phases overlap across the workgroups of a CU: a difference is what a phase ADDS to the launch)", "",
+                  f"* staging + one list pass {t(one):.3f}; list over 174 frequencies {t(esc) - t(one):+.3f}; straight line through the grid sizes: "
+                  f"{tfixed:.3f} + {tslope * 1e3:.1f} us per wave-iteration; config 3 {t(full):.3f} (nothing queued: {t(noq):.3f})", ""]
     out = os.path.join(ROOT, "profiles", f"{tag}_config3_budget.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
