@@ -423,6 +423,47 @@ def host_buffer_leg(library, freq, alt, den, bmag, bpsi, mode, n_points, math, k
                     "about the link)"}
 
 
+def devices_all_child(n_visible):
+    """(child process of the default run) config 4's rows, 12 500 per visible GPU, through
+    vertical_forward_operator(..., devices="all") on NumPy arrays; prints one JSON object."""
+    import torch
+
+    from pyrayhf_amd import library, synth
+    dev = torch.device("cuda", 0)
+    rows_all = 12500 * n_visible
+    a_t, d_t, b_t, p_t = synth.chapman_profiles_torch(max(rows_all, 100000), 20260004, dev, rows=slice(0, rows_all))
+    host = [x.cpu().numpy() for x in (d_t, b_t, p_t)]
+    alt = a_t.cpu().numpy()
+    del d_t, b_t, p_t
+    f4 = synth.sounder_frequencies(4)
+    library.vertical_forward_operator(f4, *host, alt, "X", 20000, devices="all")         # (arenas grow)
+    t3 = time.perf_counter()
+    out = library.vertical_forward_operator(f4, *host, alt, "X", 20000, devices="all")
+    dt3 = time.perf_counter() - t3
+    print(json.dumps({"gpus": n_visible, "profiles": rows_all, "ms_per_call": 1e3 * dt3,
+                      "integrals_per_s": rows_all * f4.size / dt3, "finite_fraction": float(np.isfinite(out).mean()),
+                      "note": "vertical_forward_operator(..., devices='all') on NumPy arrays: in-process threads, one per GPU; "
+                              "PCIe-inclusive; never `value`"}))
+
+
+def devices_all_leg(n_visible, limit_s=150):
+    import signal
+    cmd = [sys.executable, os.path.abspath(__file__), "--devices-all-child", str(n_visible)]
+    try:
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, start_new_session=True)
+        try:
+            out, _ = child.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)
+            child.wait()
+            return {"error": f"no answer within {limit_s} s (child ended)"}
+        if child.returncode != 0:
+            return {"error": f"child exit code {child.returncode}"}
+        return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    except Exception as exc:       # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def arm_watchdog(seconds, what, rank):
     """A hung collective set-up must end with a message and a non-zero exit, not with the driver's time limit: after
     `seconds` the process says what it was waiting for and leaves (os._exit: no exec, no re-launch)."""
@@ -539,7 +580,12 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: initialise the process group anyway and push the result rows through the real "
                          "all_gather_into_tensor (RCCL with one rank) - the N > 1 code path on one GPU")
+    ap.add_argument("--devices-all-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.devices_all_child:
+        devices_all_child(args.devices_all_child)
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
@@ -851,23 +897,9 @@ def main():
             # More than one GPU visible to a single process: the drop-in call's own multi-GPU path (devices="all": one
             # host thread and one context per GPU, contiguous row blocks, no process group, no collective) on config 4's
             # rows, 12 500 per GPU, from NumPy arrays.  PCIe-inclusive; beside the RCCL ranks' figure, never `value`.
-            try:
-                rows_all = 12500 * n_visible
-                a_t, d_t, b_t, p_t = synth.chapman_profiles_torch(max(rows_all, 100000), 20260004, dev, rows=slice(0, rows_all))
-                host = [x.cpu().numpy() for x in (d_t, b_t, p_t)]
-                del d_t, b_t, p_t
-                f4 = synth.sounder_frequencies(4)
-                library.vertical_forward_operator(f4, *host, a_t.cpu().numpy(), "X", 20000, devices="all")    # arenas grow
-                t3 = time.perf_counter()
-                library.vertical_forward_operator(f4, *host, a_t.cpu().numpy(), "X", 20000, devices="all")
-                dt3 = time.perf_counter() - t3
-                result["devices_all"] = {"gpus": n_visible, "profiles": rows_all, "ms_per_call": 1e3 * dt3,
-                                         "integrals_per_s": rows_all * f4.size / dt3,
-                                         "note": "vertical_forward_operator(..., devices='all') on NumPy arrays: in-process threads, "
-                                                 "one per GPU; PCIe-inclusive; never `value`"}
-                del host
-            except Exception as exc:       # noqa: BLE001
-                result["devices_all"] = {"error": f"{type(exc).__name__}: {exc}"}
+            # In a child process with a time limit: this path has never run on more than one GPU, and a hang in it
+            # must not cost the headline line.
+            result["devices_all"] = devices_all_leg(n_visible)
 
         if world == 1 and not args.no_cpu_baseline:
             # bounded samples of the same workload (for config 5: its X/20000 slice, where the CPU time goes)

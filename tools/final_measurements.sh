@@ -2,7 +2,7 @@
 # Everything profiles/ cites for a round, in one or two gpurun calls: bench lines (default with legs and CPU legs,
 # config 3, config 5, two-rank rehearsal, one-rank RCCL), cost splits, O-mode reports, rocprof trace + PMC passes.
 # Usage (on the GPU box, from the repo root): tools/final_measurements.sh r03 [part]     part: bench | profiles | all
-TAG=${1:-r03}
+TAG=${1:-r05}
 PART=${2:-all}
 OUT=gpurun_out/final_$TAG; mkdir -p $OUT
 if [ "$PART" = "bench" ] || [ "$PART" = "all" ]; then
@@ -17,6 +17,7 @@ PRHF_BENCH_BACKEND=gloo python bench.py --gpus 4 --profiles 256 --steps 3 --no-c
 PRHF_BENCH_BACKEND=gloo python bench.py --gpus 4 --workload config5 --profiles 256 --steps 3 --no-cpu-baseline --no-single-profile --no-legs > $OUT/bench_${TAG}_config5_n4_rehearsal.json 2> $OUT/bench_c5n4.err; echo "c5 n4 rc=$?"
 python tools/tracer_workload.py > $OUT/bench_tracers_$TAG.jsonl 2>/dev/null
 python tools/tracer_fan_workload.py > $OUT/bench_tracer_fan_$TAG.jsonl 2>/dev/null
+python bench.py --devices-all-child 1 > $OUT/devices_all_one_gpu_$TAG.json 2>/dev/null; echo "devices=all child rc=$?"
 python tools/stage_cost3.py > $OUT/stage_cost3_$TAG.jsonl 2>/dev/null
 python tools/bench_generic_path.py > $OUT/bench_generic_path_$TAG.jsonl 2>/dev/null
 python tools/time_dropin.py > $OUT/time_dropin_$TAG.jsonl 2>/dev/null
@@ -30,6 +31,7 @@ tools/profile.sh ${TAG}_config4 > /dev/null 2>&1; echo "prof config4 done"
 tools/profile.sh ${TAG}_config3 --workload config3 > /dev/null 2>&1; echo "prof config3 done"
 tools/profile.sh ${TAG}_config5 --workload config5 > /dev/null 2>&1; echo "prof config5 done"
 tools/profile.sh ${TAG}_config2 --profiles 1 --freqs 174 > /dev/null 2>&1; echo "prof config2 done"
-PROF_CMD="python3 tools/tracer_workload.py" tools/profile.sh ${TAG}_snell > /dev/null 2>&1; echo "prof snell done"
+tools/f_row_profile.sh ${TAG} > /dev/null 2>&1; echo "prof tracers (f-row legs) done"
+tools/inst_budget3.sh ${TAG} > /dev/null 2>&1; echo "config 3 instruction budget done"
 fi
 echo "final measurements done"
