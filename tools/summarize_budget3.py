@@ -95,7 +95,10 @@ def main():
                   f"what the ill-conditioned points cost (default minus `well_conditioned = 0`, which queues nothing): **{v(full) - v(noq):.0f}**", "",
                   "## The same split in time (ms per launch; phases overlap across the workgroups of a CU: a difference is what a phase ADDS to the launch)", "",
                   f"* staging + one list pass {t(one):.3f}; list over 174 frequencies {t(esc) - t(one):+.3f}; straight line through the grid sizes: "
-                  f"{tfixed:.3f} + {tslope * 1e3:.1f} us per wave-iteration; config 3 {t(full):.3f} (nothing queued: {t(noq):.3f})", ""]
+                  f"{tfixed:.3f} + {tslope * 1e3:.1f} us per wave-iteration; config 3 {t(full):.3f}.  (The `well_conditioned = 0` launch, "
+                  f"{t(noq):.3f} ms, is an instruction count only: with nothing queued the points next to the reflection height stay in the "
+                  "reduced algebra, a pair's sum comes out infinite there and its whole item - eight pairs - is evaluated again point by "
+                  "point by one wave while the workgroup waits: a serial path that sane settings never take.)", ""]
     out = os.path.join(ROOT, "profiles", f"{tag}_config3_budget.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
