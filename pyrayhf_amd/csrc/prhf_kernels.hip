@@ -171,8 +171,12 @@ __device__ __forceinline__ double rsqrt_cubic(double x) {
     return __builtin_fma(y * e, p, y);                     // y (1 + e/2 + 3 e^2/8)
 }
 
-// One Newton step instead: 2^-48 (measured).  Enough for X mode, whose answer is conditioned
-// like its inputs (the reference's own +-1 ulp response is 3e-11); not used for O mode.
+// One Newton step instead: 2^-48 (measured).  Enough for X mode, whose answer is conditioned like its inputs (the
+// reference's own +-1 ulp response is 3e-11) - and, since round 5, for the reduced algebra in O mode as well, which
+// is only taken where 1 - X > 1e-5: there the 3.5e-15 it leaves in beta and w move a virtual height by ~2e-12 (median
+// distance from the reference on 35 000 pairs of config 3: 2.4e-12 -> 4.3e-12; share within 1e-6, worst pair and the
+// counts under the reference's own noise rule unchanged: profiles/omode_onewton_r05.txt) for one instruction less per
+// rsqrt - config 3 -2.5 %, O/500 -3.5 %, O/2000 and O/20000 -2.5 ... -4 % (profiles/ab_r05_onewton.txt).
 __device__ __forceinline__ double rsqrt_newton(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double t = x * y;
@@ -182,7 +186,11 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 
 template <int MODE>
 __device__ __forceinline__ double rsqrt_tier(double x) {
-    return MODE == PRHF_KMODE_O ? rsqrt_cubic(x) : rsqrt_newton(x);
+#ifdef PRHF_O_CUBIC
+    return MODE == PRHF_KMODE_O ? rsqrt_cubic(x) : rsqrt_newton(x);     // (rounds 1 - 4: the third-order step in O mode)
+#else
+    return rsqrt_newton(x);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

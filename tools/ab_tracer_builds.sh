@@ -1,7 +1,9 @@
 #!/bin/bash
-# tracer workloads under three builds, interleaved twice
+# Tracer workloads (200 000 random rays per-ray; fans of 204 800) under several builds of the library, interleaved twice.
+# Usage: tools/ab_tracer_builds.sh [lib ...]     (default: the in-tree library and build/ab/libprhf_r05f.so)
+LIBS=${@:-pyrayhf_amd/libprhf.so build/ab/libprhf_r05f.so}
 for rnd in 1 2; do
-for lib in pyrayhf_amd/libprhf.so build/ab/libprhf_r05f.so build/ab/libprhf_sw5.so; do
+for lib in $LIBS; do
   echo "== $lib"
   PRHF_LIB=$PWD/$lib python tools/tracer_workload.py 2>/dev/null | grep "^{" | cut -c1-200
   PRHF_LIB=$PWD/$lib python tools/tracer_fan_workload.py 2>/dev/null | grep "^{" | python -c "
