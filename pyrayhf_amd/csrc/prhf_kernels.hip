@@ -184,13 +184,13 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
     return __builtin_fma(y * e, 0.5, y);                   // y (1 + e/2)
 }
 
-template <int MODE>
+// THIRD: the third-order step.  The reduced algebra takes it in O mode where nothing guards its use (the opt-in "fast"
+// tier everywhere: next to reflection, where 1 - X is tiny, the Newton step's 3.5e-15 would show - share of config-like
+// pairs within 1e-6 of the reference 98.0 % -> 96.0 %) and the Newton step where 1 - X > 1e-5 is checked (the default
+// O-mode arithmetic's main loops), in X mode and in the tracers' guarded levels.
+template <bool THIRD>
 __device__ __forceinline__ double rsqrt_tier(double x) {
-#ifdef PRHF_O_CUBIC
-    return MODE == PRHF_KMODE_O ? rsqrt_cubic(x) : rsqrt_newton(x);     // (rounds 1 - 4: the third-order step in O mode)
-#else
-    return rsqrt_newton(x);
-#endif
+    return THIRD ? rsqrt_cubic(x) : rsqrt_newton(x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -293,7 +293,7 @@ __device__ __forceinline__ void index_faithful(double X, double Y, double psi_de
 // below, mu^2 < 0 makes w (and with it q) NaN.  Hence: keep the point iff q > kQCliff.
 constexpr double kQCliff = -3.3306690738754696e-16;   // -1.5 * 2^-52
 
-template <int MODE>
+template <int MODE, bool THIRD = (MODE == PRHF_KMODE_O)>
 __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, double* mu_out,
                                                 double* mup_out, double* q_out) {
 #pragma clang fp contract(fast)
@@ -305,11 +305,11 @@ __device__ __forceinline__ void index_fast_core(double X, double Y2, double S2, 
     const double h2 = h * h;
     const double t = YL2 * Xm1;
     const double alpha = h2 + t * Xm1;
-    const double rbeta = rsqrt_tier<MODE>(alpha);
+    const double rbeta = rsqrt_tier<THIRD>(alpha);
     const double D = (Xm1 - h) + sgn * (alpha * rbeta);
     const double XXm1 = X * Xm1;
     const double N = D - XXm1;
-    const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
+    const double w = rsqrt_tier<THIRD>(N * D);                 // NaN when mu^2 < 0 (:233)
     const double Nw = N * w;
     const double mu = __builtin_fabs(Nw);
     // q = X(1-X)/D = 1 - mu^2.  The callers test q against the mu > 1 cliff at the 1e-16 level and need its
@@ -823,7 +823,7 @@ __device__ __forceinline__ double point_mup(const Node& nd, double dz, double f_
 // The difference costs h an absolute error of 1e-16 Y^2 where psi is small - and there h itself no longer matters.
 // 28 instructions from (den, Y^2/2, C2) - with Y^2/2 = (cY2/2) b^2 (two more) 30: 16 FMA, 11 MUL, 1 ADD,
 // 2 v_rsq_f64 (the version through X needed 34).
-template <int MODE>
+template <int MODE, bool THIRD>
 __device__ __forceinline__ double group_index_lean(double den, double hY2, double C2, double cX, double* a_out) {
 #pragma clang fp contract(fast)
     constexpr double sgn = (MODE == PRHF_KMODE_O) ? 1.0 : -1.0;
@@ -833,11 +833,11 @@ __device__ __forceinline__ double group_index_lean(double den, double hY2, doubl
     const double t = a * YL2;
     const double ta = t * a;
     const double alpha = __builtin_fma(h, h, ta);
-    const double rbeta = rsqrt_tier<MODE>(alpha);
+    const double rbeta = rsqrt_tier<THIRD>(alpha);
     const double G = __builtin_fma(sgn * alpha, rbeta, -h);    // s beta - h
     const double D = a + G;
     const double N = __builtin_fma(a, a, G);                   // D - X (1 - X)
-    const double w = rsqrt_tier<MODE>(N * D);                  // NaN when mu^2 < 0 (:233)
+    const double w = rsqrt_tier<THIRD>(N * D);                 // NaN when mu^2 < 0 (:233)
     const double DmX = __builtin_fma(-cX, den, D);
     const double v = __builtin_fma(-0.5, ta, t);               // t (1 + X) / 2 = t (1 - a / 2): t a is there already
     const double Sp1 = __builtin_fma(sgn * v, rbeta, 1.0);     // 1 + s t (1 + X) / (2 beta)
@@ -990,7 +990,7 @@ __device__ __forceinline__ double lean_step(double2 g, double span, double a0, d
                        : (POLY == 2 ? ua.x + x * (ua.y + x * ub.x) : ua.x + x * (ua.y + x * (ub.x + x * ub.y)));
     }
     double a;
-    const double mup = group_index_lean<MODE>(den, hcY2 * (b * b), C2, cX, &a);
+    const double mup = group_index_lean<MODE, MODE == PRHF_KMODE_O && !CHECK>(den, hcY2 * (b * b), C2, cX, &a);
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
 }
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ double lean_step_top(double2 g, const TopSegment& t, 
     const double C2 = POLY == 1 ? t.q0 + m0 * t.q1
                     : (POLY == 2 ? t.q0 + m0 * (t.q1 + m0 * t.q2) : t.q0 + m0 * (t.q1 + m0 * (t.q2 + m0 * t.q3)));
     double a;
-    const double mup = group_index_lean<MODE>(den, Y * Y, C2, cX, &a);
+    const double mup = group_index_lean<MODE, MODE == PRHF_KMODE_O && !CHECK>(den, Y * Y, C2, cX, &a);
     (void)hcY2;
     if (CHECK) viol |= __ballot(!(a > wc));
     return __builtin_fma(mup, g.y, acc);
