@@ -1455,7 +1455,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     }
     a.resident_cus = c->cu_count;
     {
-        int rc2 = ensure(c, c->partial, (size_t)n_prof * 16);      // per-profile scalars (the operator's chunk scratch is free here)
+        int rc2 = ensure(c, c->partial, (size_t)n_prof * 32);      // per-profile scalars (the operator's chunk scratch is free here)
         if (rc2 != PRHF_OK) return rc2;
         a.prof_info = static_cast<double*>(c->partial.p);
         a.n_prof = n_prof;

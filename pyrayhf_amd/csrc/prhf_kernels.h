@@ -261,7 +261,8 @@ struct SnellArgs {
     // Per-ray launch: persistent (ray_queue: next batch of rays - gridDim.x, zero at launch)
     unsigned* ray_queue;
     int resident_cus;            // multiprocessors of the device (sizes the persistent grid)
-    double* prof_info;           // (n_prof, 2) scratch: max|B| and "has a negative density", filled by launch_snell
+    double* prof_info;           // (n_prof, 4) scratch: max|B|, "has a negative density", the level of the largest density (a
+                                 // hint: where a ray that escapes would have come closest to turning), filled by launch_snell
     // Per-profile level table (or null), filled by launch_snell: what a level's mu and mu' need that does not depend on
     // the frequency - f_N^2 = (sqrt(den) c_p)^2, g_p |B|, sin(psi), cos(psi) - so that a ray pays two quotients and
     // the Appleton-Hartree algebra per level instead of a square root and a correctly rounded sine / cosine on top
