@@ -1365,10 +1365,13 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     const bool grouped = ray_group != nullptr;
     if (grouped && n_groups < 1) return fail(PRHF_EINVAL, "a grouped launch needs at least one group");
     const int64_t n_keys = grouped ? n_groups : n_rays;          // entries of freq_hz / profile_index
-    const size_t level_bytes = grouped ? (size_t)n_groups * (size_t)(n_alt + 1) * 16 : 0;
+    // per group and level: mu, mu' (16 B), the compacted entry (32 B), its grid level (4 B); per group: four scalars
+    const size_t level_cells = grouped ? (size_t)n_groups * (size_t)(n_alt + 1) : 0;
+    const size_t level_bytes = level_cells * 52 + (grouped ? (size_t)n_groups * 16 : 0);
     if (level_bytes > ((size_t)4 << 30))
         return fail(PRHF_EINVAL, "level table of %lld groups exceeds 4 GiB: trace in batches", (long long)n_groups);
     if (n_rays < 0 || n_prof < 1 || n_alt < 2 || n_alt > 3000) return fail(PRHF_EINVAL, "bad shape");
+    if (grouped && n_prof > 0x7fffffffLL) return fail(PRHF_EINVAL, "a grouped launch takes at most 2^31 - 1 profiles");
     if ((path_x == nullptr) != (path_z == nullptr)) return fail(PRHF_EINVAL, "path_x and path_z go together");
     if (path_x && path_stride < 2 * (n_alt + 1) - 1)
         return fail(PRHF_EINVAL, "path_stride must hold 2 (n_alt + 1) - 1 nodes");
@@ -1448,6 +1451,9 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         int rc3 = ensure(c, c->levels, level_bytes);
         if (rc3 != PRHF_OK) return rc3;
         a.levels = static_cast<double*>(c->levels.p);
+        a.group_entries = a.levels + 2 * level_cells;
+        a.group_info = reinterpret_cast<int*>(a.group_entries + 4 * level_cells);
+        a.group_kidx = a.group_info + 4 * (size_t)n_groups;
     } else {
         a.freq_hz = d_keyf; a.prof_idx = d_keyp;
         // per-ray launch: persistent wavefronts drawing rays from a queue
