@@ -12,6 +12,8 @@ alt, den, bmag, bpsi = synth.chapman_profiles(256, 7)
 rng = np.random.default_rng(0)
 R = 200000
 f = rng.uniform(2e6, 14e6, R); e = rng.uniform(5.0, 89.0, R); idx = rng.integers(0, 256, R)
+if os.environ.get("PRHF_SORT_RAYS"):      # rays in profile order (what binning them before the launch would buy)
+    idx = np.sort(idx)
 ctx = _native.context(0)
 for name, fn in (("cartesian", tracers.trace_rays_cartesian_snells), ("spherical", tracers.trace_rays_spherical_snells)):
     for rep in range(3):
