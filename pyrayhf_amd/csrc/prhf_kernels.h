@@ -291,7 +291,8 @@ struct SnellArgs {
 };
 hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
 // wavefronts of the per-ray kernel that one device keeps resident; cu_count: multiprocessors of the device
-hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false, bool reduced = false);
+hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false, bool reduced = false,
+                                int geometry = 0);
 
 // residual / cost may be null
 hipError_t launch_residual(const double* vh_model, const double* vh_obs, long long n_prof, int n_freq,
