@@ -215,6 +215,52 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
 
 
 @pytest.mark.parametrize("spherical", [False, True])
+def test_fan_bracket_by_running_minimum_on_odd_columns(spherical):
+    """The grouped launch finds the reference's bracket (library.py:1085-1093 / :1598-1603: the FIRST pair of consecutive
+    finite levels with crit[i] >= p >= crit[i + 1]) as the first entry whose running minimum of the criterion is <= p
+    (prhf_snell.inc snell_ray_table), checks the pair against the reference's condition and walks the list when the
+    check fails.  Held against the per-ray launch in the reference's operation order, which walks the levels itself:
+    a valley that blanks levels between two layers, a layer of vacuum, an unmagnetised column, a column whose
+    criterion is NaN at one level (a NaN altitude: the walk's case), elevations at and beyond the ends of [0, 90]."""
+    from pyrayhf_amd import library, synth, tracers
+    alt, den, bmag, bpsi = synth.chapman_profiles(6, 31)
+    z = alt if alt.ndim == 1 else alt[0]
+    den = den.copy()
+    den[1] += 2.5 * den[1].max() * np.exp(-0.5 * ((z - 110.0) / 6.0) ** 2)      # an E layer denser than the F peak: a blanked band
+    den[2, 90:130] = 0.0                                                          # vacuum in the column
+    bmag = bmag.copy(); bmag[3] = 0.0
+    grids = [alt]
+    if spherical:
+        odd = np.array(alt, dtype=float, copy=True)
+        odd[..., 140] = np.nan
+        grids.append(odd)
+    freqs = np.linspace(1.5e6, 14e6, 26)
+    elevs = np.concatenate([np.linspace(0.0, 90.0, 31), [89.99, 90.5, -3.0]])
+    fan_fn = tracers.trace_fan_spherical_snells if spherical else tracers.trace_fan_cartesian_snells
+    ray_fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+    pp, ff, ee = np.meshgrid(np.arange(6), freqs, elevs, indexing="ij")
+    turned = 0
+    for grid in grids:
+        for mode in "OX":
+            fan = fan_fn(freqs, elevs, grid, den, bmag, bpsi, mode, return_paths=True)
+            rays = ray_fn(ff.ravel(), ee.ravel(), grid, den, bmag, bpsi, mode, profile_index=pp.ravel(), return_paths=True,
+                          math=library.MATH_FAITHFUL)
+            for key in ("group_path_km", "group_delay_sec", "ground_range_km", "x_turn_km", "z_turn_km", "x_midpoint",
+                        "z_midpoint", "n_path", "x", "z"):
+                got, want = fan[key].reshape(rays[key].shape), rays[key]
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (mode, key)
+                if key == "n_path":
+                    assert np.array_equal(got, want), (mode, key)
+                else:
+                    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12, equal_nan=True, err_msg=f"{mode} {key}")
+            turned += int(np.isfinite(rays["group_path_km"]).sum())
+            # every profile has rays that turn and rays that escape
+            per_prof = np.isfinite(fan["group_path_km"]).reshape(6, -1)
+            assert per_prof.any(axis=1).all() and (~per_prof).any(axis=1).all()
+    assert turned > 3000
+
+
+@pytest.mark.parametrize("spherical", [False, True])
 def test_per_profile_level_table_changes_no_bit(spherical):
     """Option snell_table: f_N^2, g_p |B|, sin(psi), cos(psi) of every level once per profile (snell_profile_kernel)
     instead of per ray and level - hoisted, not changed: the rays of the per-ray call, of the grouped call and their
