@@ -275,13 +275,17 @@ int prhf_snell_spherical_f64(prhf_ctx* ctx, const double* freq_hz, const double*
 /*
  * Fans of rays: many elevations per (profile, frequency).  The tracers above evaluate the Appleton-Hartree index
  * level by level for every ray (library.py:1184-1189 / :1566-1571) although it depends on the profile and the
- * frequency only; here the n_groups (profile, frequency) groups get their level table once (one thread per group
- * and level) and every ray reads the table of its group: group_freq_hz[g] [Hz], group_profile_index[g] (NULL:
+ * frequency only; here the n_groups (profile, frequency) groups get their tables once - mu and mu' of every level
+ * (one thread per group and level, the reference's operation order) and the list of the levels with a finite mu,
+ * compacted, with the running minimum of the turning-point criterion, so that a ray finds its bracket
+ * (library.py:1085-1093 / :1598-1603: the first pair of consecutive finite levels the invariant falls between) with
+ * two loads - and every ray reads the tables of its group: group_freq_hz[g] [Hz], group_profile_index[g] (NULL:
  * profile 0), ray_group[r] in [0, n_groups), elevation_deg[r].  geometry 0: flat Earth (the four controls are
- * ignored), 1: spherical Earth.  Outputs, paths, flags and errors as for the per-ray calls; the results are bit
- * for bit those of the per-ray calls on the same rays.  PRHF_EINVAL when the level table
- * (n_groups x (n_alt + 1) x 16 bytes) would exceed 4 GiB, and - checked on the host for host buffers, by the kernel
- * for device-resident arrays (reported at the synchronisation) - when a ray_group or a profile index is out of range.
+ * ignored), 1: spherical Earth.  Outputs, paths, flags and errors as for the per-ray calls; the results are those of
+ * the per-ray calls on the same rays in PRHF_MATH_FAITHFUL to 1e-15 (other orders of summation).  PRHF_EINVAL when the
+ * tables (n_groups x (n_alt + 1) x 52 bytes in the context's scratch) would exceed 64 GiB, and - checked on the host
+ * for host buffers, by the kernel for device-resident arrays (reported at the synchronisation) - when a ray_group or
+ * a profile index is out of range.
  */
 int prhf_snell_fan_f64(prhf_ctx* ctx, int32_t geometry, const double* group_freq_hz,
                        const int64_t* group_profile_index, int64_t n_groups, const int64_t* ray_group,

@@ -1368,8 +1368,9 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     // per group and level: mu, mu' (16 B), the compacted entry (32 B), its grid level (4 B); per group: four scalars
     const size_t level_cells = grouped ? (size_t)n_groups * (size_t)(n_alt + 1) : 0;
     const size_t level_bytes = level_cells * 52 + (grouped ? (size_t)n_groups * 16 : 0);
-    if (level_bytes > ((size_t)4 << 30))
-        return fail(PRHF_EINVAL, "level table of %lld groups exceeds 4 GiB: trace in batches", (long long)n_groups);
+    if (level_bytes > ((size_t)64 << 30) || n_groups > 0x7fffffffLL || (grouped && n_rays > 0x7fffffffLL))
+        return fail(PRHF_EINVAL, "level tables of %lld groups exceed 64 GiB (or 2^31 - 1 groups / rays): trace in batches",
+                    (long long)n_groups);
     if (n_rays < 0 || n_prof < 1 || n_alt < 2 || n_alt > 3000) return fail(PRHF_EINVAL, "bad shape");
     if (grouped && n_prof > 0x7fffffffLL) return fail(PRHF_EINVAL, "a grouped launch takes at most 2^31 - 1 profiles");
     if ((path_x == nullptr) != (path_z == nullptr)) return fail(PRHF_EINVAL, "path_x and path_z go together");
