@@ -1458,14 +1458,17 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     } else {
         a.freq_hz = d_keyf; a.prof_idx = d_keyp;
         // per-ray launch: persistent wavefronts drawing rays from a queue
-        a.ray_queue = c->d_status + 6;
+        a.ray_queue = nullptr;                                     // (set below: behind the per-profile scalars)
     }
     a.resident_cus = c->cu_count;
     {
-        int rc2 = ensure(c, c->partial, (size_t)n_prof * 32);      // per-profile scalars (the operator's chunk scratch is free here)
+        // per-profile scalars (the operator's chunk scratch is free here); behind them the per-ray launch's queue counters
+        const size_t info_bytes = (((size_t)n_prof * 32 + 127) / 128) * 128;
+        int rc2 = ensure(c, c->partial, info_bytes + prhf::snell_queue_bytes());
         if (rc2 != PRHF_OK) return rc2;
         a.prof_info = static_cast<double*>(c->partial.p);
         a.n_prof = n_prof;
+        if (!grouped) a.ray_queue = reinterpret_cast<unsigned*>(static_cast<char*>(c->partial.p) + info_bytes);
     }
     a.ptab = nullptr;
     if (c->knobs.snell_table > 0 && (double)n_keys >= c->knobs.snell_table * (double)n_prof && prof_elems * 32 <= ((size_t)1 << 30)) {

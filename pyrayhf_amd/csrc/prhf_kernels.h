@@ -264,7 +264,7 @@ struct SnellArgs {
     int* group_kidx;             // (n_groups, n_alt + 1) grid level of each entry
     int* group_info;             // (n_groups, 4) entries, "ground level inserted", error bits (1 profile index, 2 negative
                                  // density), profile
-    // Per-ray launch: persistent (ray_queue: next batch of rays - gridDim.x, zero at launch)
+    // Per-ray launch: persistent wavefronts drawing rays from queues (snell_queue_bytes() of counters, zeroed by launch_snell)
     unsigned* ray_queue;
     int resident_cus;            // multiprocessors of the device (sizes the persistent grid)
     double* prof_info;           // (n_prof, 4) scratch: max|B|, "has a negative density", the level of the largest density (a
@@ -289,6 +289,7 @@ struct SnellArgs {
     double apex_boost;
     int max_substeps;
 };
+size_t snell_queue_bytes();            // the per-ray launch's queue counters (SnellArgs::ray_queue, 128-byte aligned)
 hipError_t launch_snell(const SnellArgs& a, hipStream_t stream);   // with a.ray_group: level table kernel first
 // wavefronts of the per-ray kernel that one device keeps resident; cu_count: multiprocessors of the device
 hipError_t snell_resident_waves(long long n_alt, int cu_count, long long* waves, bool ptab = false, bool reduced = false,
