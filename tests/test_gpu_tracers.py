@@ -215,6 +215,30 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
 
 
 @pytest.mark.parametrize("spherical", [False, True])
+def test_ray_queues_give_every_ray_its_result_whatever_the_count(spherical):
+    """The per-ray launch is persistent: wavefronts draw their rays four at a time from eight queues, one per slice of
+    the rays (prhf_snell.inc snell_dispatch).  Ray counts that are multiples of nothing, below and above the number of
+    slices, the batch and the resident wavefronts: every ray comes out as in the launch of all 30 011 (the reference's
+    operation order, where the per-profile table - taken from 4 rays per profile on - changes no bit)."""
+    from pyrayhf_amd import library, synth, tracers
+    alt, den, bmag, bpsi = synth.chapman_profiles(16, 3)
+    rng = np.random.default_rng(9)
+    R = 30011
+    f = rng.uniform(2e6, 14e6, R); e = rng.uniform(1.0, 90.0, R); idx = rng.integers(0, 16, R)
+    fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+    keys = ("group_path_km", "group_delay_sec", "ground_range_km", "x_midpoint", "z_midpoint", "n_path")
+    whole = fn(f, e, alt, den, bmag, bpsi, "O", profile_index=idx, math=library.MATH_FAITHFUL)
+    assert 0.3 < np.isfinite(whole["group_path_km"]).mean() < 0.95
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 65, 257, 4099, 20481):
+        part = fn(f[:n], e[:n], alt, den, bmag, bpsi, "O", profile_index=idx[:n], math=library.MATH_FAITHFUL)
+        for key in keys:
+            assert np.array_equal(part[key], whole[key][:n], equal_nan=True), (n, key)
+    tail = fn(f[-1777:], e[-1777:], alt, den, bmag, bpsi, "O", profile_index=idx[-1777:], math=library.MATH_FAITHFUL)
+    for key in keys:
+        assert np.array_equal(tail[key], whole[key][-1777:], equal_nan=True), key
+
+
+@pytest.mark.parametrize("spherical", [False, True])
 def test_fan_bracket_by_running_minimum_on_odd_columns(spherical):
     """The grouped launch finds the reference's bracket (library.py:1085-1093 / :1598-1603: the FIRST pair of consecutive
     finite levels with crit[i] >= p >= crit[i + 1]) as the first entry whose running minimum of the criterion is <= p
