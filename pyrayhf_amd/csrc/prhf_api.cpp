@@ -1408,6 +1408,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     const double* d_keyf = nullptr;
     const long long* d_keyp = nullptr;
     const long long* d_group = nullptr;
+    bool small_out = false;                    // a small host-buffer call: the kernel writes its results into pinned host memory
     if (dev) {
         a.den = den; a.bmag = bmag; a.bpsi = bpsi; a.alt = alt; a.elev_deg = elevation_deg;
         d_keyf = freq_hz;
@@ -1431,21 +1432,53 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         double* d_out = p; p += PRHF_SNELL_OUTPUTS * (size_t)n_rays;
         double* d_px = path_x ? p : nullptr; p += path_elems;
         double* d_pz = path_x ? p : nullptr;
-        HIP_TRY(hipMemcpyAsync(d_den, den, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_bmag, bmag, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_alt, alt, alt_elems * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_f, freq_hz, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_e, elevation_deg, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
-        if (profile_index)
-            HIP_TRY(hipMemcpyAsync(d_i, profile_index, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
-        if (grouped)
-            HIP_TRY(hipMemcpyAsync(d_g, ray_group, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        // A small call (the reference's own: ONE ray, its path arrays back): six to eight uploads from pageable memory
+        // and three copies back cost several times the kernels.  As in run(): the inputs are packed in the arena's own
+        // order and sent in one piece - or, on a large-BAR device with the arena idle, written straight into it by the
+        // CPU - and the kernel writes the results into pinned host memory that the device sees (the upper half of the
+        // pack buffer).
+        double* base = static_cast<double*>(c->arena.p);
+        const size_t in_elems = (size_t)(d_out - base);
+        const size_t out_elems = PRHF_SNELL_OUTPUTS * (size_t)n_rays + 2 * path_elems;
+        small_out = c->h_pack && in_elems * 8 <= kPackBytes / 2 && out_elems * 8 <= kPackBytes / 4;
+        if (small_out) {
+            const bool direct = c->large_bar && c->knobs.direct_upload != 0 && in_elems * 8 <= kDirectBytes &&
+                                hipStreamQuery(c->stream) == hipSuccess &&
+                                (!c->timed || hipEventQuery(c->end_ev()) == hipSuccess);
+            (void)hipGetLastError();               // (hipErrorNotReady from the two queries is not an error)
+            double* h = direct ? base : c->h_pack;
+            std::memcpy(h + (d_den - base), den, prof_elems * 8);
+            std::memcpy(h + (d_bmag - base), bmag, prof_elems * 8);
+            std::memcpy(h + (d_bpsi - base), bpsi, prof_elems * 8);
+            std::memcpy(h + (d_alt - base), alt, alt_elems * 8);
+            std::memcpy(h + (d_f - base), freq_hz, (size_t)n_keys * 8);
+            std::memcpy(h + (d_e - base), elevation_deg, (size_t)n_rays * 8);
+            if (profile_index) std::memcpy(h + (reinterpret_cast<double*>(d_i) - base), profile_index, (size_t)n_keys * 8);
+            if (grouped) std::memcpy(h + (reinterpret_cast<double*>(d_g) - base), ray_group, (size_t)n_rays * 8);
+            if (direct) _mm_sfence();
+            else HIP_TRY(hipMemcpyAsync(base, h, in_elems * 8, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_den, den, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_bmag, bmag, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_bpsi, bpsi, prof_elems * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_alt, alt, alt_elems * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_f, freq_hz, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_e, elevation_deg, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+            if (profile_index)
+                HIP_TRY(hipMemcpyAsync(d_i, profile_index, (size_t)n_keys * 8, hipMemcpyHostToDevice, c->stream));
+            if (grouped)
+                HIP_TRY(hipMemcpyAsync(d_g, ray_group, (size_t)n_rays * 8, hipMemcpyHostToDevice, c->stream));
+        }
         a.den = d_den; a.bmag = d_bmag; a.bpsi = d_bpsi; a.alt = d_alt; a.elev_deg = d_e;
         d_keyf = d_f;
         d_keyp = profile_index ? d_i : nullptr;
         d_group = grouped ? d_g : nullptr;
         a.out = d_out; a.path_x = d_px; a.path_z = d_pz;
+        if (small_out) {
+            a.out = c->h_pack_dev + kPackBytes / 16;               // doubles: byte offset kPackBytes / 2
+            a.path_x = path_x ? a.out + PRHF_SNELL_OUTPUTS * (size_t)n_rays : nullptr;
+            a.path_z = path_x ? a.path_x + path_elems : nullptr;
+        }
     }
     if (grouped) {
         a.ray_group = d_group; a.group_freq = d_keyf; a.group_prof = d_keyp; a.n_groups = n_groups;
@@ -1481,6 +1514,16 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     HIP_TRY(hipEventRecord(c->pending_end_ev(), c->stream));
     c->mark_timed();
     c->status_pending = true;
+    if (small_out) {                                               // (written by the kernel itself into pinned memory)
+        const int rc = prhf_sync(c);
+        const double* h_out = c->h_pack + kPackBytes / 16;
+        std::memcpy(out, h_out, PRHF_SNELL_OUTPUTS * (size_t)n_rays * 8);
+        if (path_x) {
+            std::memcpy(path_x, h_out + PRHF_SNELL_OUTPUTS * (size_t)n_rays, path_elems * 8);
+            std::memcpy(path_z, h_out + PRHF_SNELL_OUTPUTS * (size_t)n_rays + path_elems, path_elems * 8);
+        }
+        return rc;
+    }
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(out, a.out, PRHF_SNELL_OUTPUTS * (size_t)n_rays * 8, hipMemcpyDeviceToHost, c->stream));
         if (path_x) {

@@ -264,7 +264,7 @@ struct SnellArgs {
     int* group_kidx;             // (n_groups, n_alt + 1) grid level of each entry
     int* group_info;             // (n_groups, 4) entries, "ground level inserted", error bits (1 profile index, 2 negative
                                  // density), profile
-    // Per-ray launch: persistent wavefronts drawing rays from queues (snell_queue_bytes() of counters, zeroed by launch_snell)
+    // Per-ray launch: persistent wavefronts drawing rays from queues (snell_queue_bytes() of counters, zeroed by the launch's first kernel)
     unsigned* ray_queue;
     int resident_cus;            // multiprocessors of the device (sizes the persistent grid)
     double* prof_info;           // (n_prof, 4) scratch: max|B|, "has a negative density", the level of the largest density (a
