@@ -1551,7 +1551,7 @@ int prhf_snell_spherical_f64(prhf_ctx* c, const double* freq_hz, const double* e
                              int64_t alt_stride_elems, int32_t mode, double earth_radius_km, double dz_target_km,
                              double apex_boost, int32_t max_substeps, double* out, double* path_x, double* path_z,
                              int64_t path_stride, uint32_t flags) {
-    if (!(earth_radius_km > 0.0) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) || max_substeps < 1)
+    if (!(earth_radius_km > 0.0) || !(earth_radius_km < 1e300) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) || max_substeps < 1)
         return fail(PRHF_EINVAL, "bad spherical tracer controls");
     const SnellGeometry geo{1, earth_radius_km, dz_target_km, apex_boost, max_substeps};
     return snell_run(c, geo, freq_hz, elevation_deg, profile_index, n_rays, den, bmag, bpsi, alt, n_prof, n_alt,
@@ -1566,7 +1566,8 @@ int prhf_snell_fan_f64(prhf_ctx* c, int32_t geometry, const double* group_freq_h
                        double* path_z, int64_t path_stride, uint32_t flags) {
     if (geometry != 0 && geometry != 1) return fail(PRHF_EINVAL, "geometry is 0 (flat Earth) or 1 (spherical Earth)");
     if (!ray_group) return fail(PRHF_EINVAL, "null array pointer");
-    if (geometry == 1 && (!(earth_radius_km > 0.0) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) || max_substeps < 1))
+    if (geometry == 1 && (!(earth_radius_km > 0.0) || !(earth_radius_km < 1e300) || !(dz_target_km > 0.0) || !(apex_boost >= 0.0) ||
+                          max_substeps < 1))
         return fail(PRHF_EINVAL, "bad spherical tracer controls");
     const SnellGeometry geo = geometry == 0 ? SnellGeometry{0, 6371.0, 1.0, 200.0, 400}
                                             : SnellGeometry{1, earth_radius_km, dz_target_km, apex_boost, max_substeps};

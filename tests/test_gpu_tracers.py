@@ -164,6 +164,11 @@ def test_spherical_single_ray_and_flat_limit():
         v_cart, v_sph = flat[key], big[key]
         assert abs(v_cart - v_sph) / max(abs(v_cart), abs(v_sph)) < 0.03, key
     assert np.nanmax(flat["z"]) > 100.0 and np.nanmax(big["z"]) > 100.0
+    for kw in ({"R_E": np.inf}, {"R_E": -6371.0}, {"R_E": np.nan}, {"dz_target_km": 0.0}, {"max_substeps": 0}):
+        with pytest.raises(ValueError, match="spherical tracer controls"):
+            tracers.trace_ray_spherical_snells(10e6, 50.0, alt_km, Ne, B, psi, "O", **kw)
+        with pytest.raises(ValueError, match="spherical tracer controls"):
+            tracers.trace_fan_spherical_snells(np.array([10e6]), np.array([50.0]), alt_km, Ne, B, psi, "O", **kw)
     esc = tracers.trace_ray_spherical_snells(30e6, 80.0, alt_km, Ne, B, psi, "O")
     assert set(esc) == {"x", "z", "group_path_km", "group_delay_sec", "x_midpoint", "z_midpoint", "ground_range_km"}
     assert all(np.isnan(v) for v in esc.values())
