@@ -247,7 +247,8 @@ int prhf_vfo_residual_f64(prhf_ctx* ctx, const double* freq_mhz, int64_t n_freq,
  * the reference's search (library.py:1248-1252), whose own rounding lands there for two rays in three and on the apex
  * for the third.  Arithmetic (prhf_ctx_set_math): PRHF_MATH_FAITHFUL evaluates mu and mu' of every level in the
  * reference's operation order (reference-run rays to 1e-12); the default evaluates levels far from reflection and from
- * the ray's turning point in the reduced algebra (within 1e-10 of the former).  Rays that never turn give NaN (node count 0).  path_x / path_z
+ * the ray's turning point in the reduced algebra (within 1e-10 of the former; spherical rays at the edge of a skip zone, one
+ * in a few million of a random set: up to 3e-10).  Rays that never turn give NaN (node count 0).  path_x / path_z
  * (optional, (n_rays, path_stride), path_stride >= 2 n_alt + 1) receive the reference's 'x' and 'z'
  * arrays padded with NaN.  Synchronous; PRHF_ENEGDEN on a negative density; PRHF_EINVAL when a
  * profile_index lies outside [0, n_prof) - checked on the host for host buffers and by the kernel for

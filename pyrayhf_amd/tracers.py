@@ -152,8 +152,9 @@ def trace_rays_cartesian_snells(f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mo
 
     ``math``: None (default) evaluates the refractive index of a level in the reduced algebra where that cannot move a
     result - far from reflection and from the ray's turning point - and in the reference's operation order elsewhere
-    (within 1e-10 of ``library.MATH_FAITHFUL``, which keeps the reference's order at every level and agrees with
-    reference-run rays to 1e-12; about three times the time).  Fans always read faithful level tables.
+    (within 1e-10 of ``library.MATH_FAITHFUL`` - on a spherical Earth one ray in a few million, at the edge of a skip
+    zone, up to 3e-10 - which keeps the reference's order at every level and agrees with reference-run rays to 1e-12;
+    about three times the time).  Fans always read faithful level tables.
     """
     return _trace_rays(False, f0_Hz, elevation_deg, alt_km, Ne, Babs, bpsi, mode, profile_index, return_paths,
                        device, math=math)
