@@ -110,6 +110,39 @@ def test_tracer_reports_a_bad_device_resident_profile_index():
             assert np.isnan(o[bad, 0]).all() and "profile_index" in _native.last_error()
 
 
+def test_fan_reports_bad_device_resident_groups_and_profile_indices():
+    """prhf_snell_fan_f64 on device-resident arrays cannot check ray_group / the groups' profile indices on the host: the
+    kernels do (snell_tables_kernel leaves the group's error bits, snell_ray_table posts the status), the call reports
+    it at its synchronisation, the rays concerned come back NaN and the others are traced - on both geometries."""
+    import torch
+    from pyrayhf_amd import _native
+    g = load_golden("g8_snell.npz")
+    prof = {k: torch.as_tensor(np.ascontiguousarray(g[f"gauss_{k}"]).reshape(1, -1), device="cuda") for k in ("den", "bmag", "bpsi")}
+    alt = torch.as_tensor(g["gauss_alt"], device="cuda")
+    n_alt = alt.numel()
+    gf = torch.tensor([5e6, 6e6], dtype=torch.float64, device="cuda")
+    e = torch.full((4,), 45.0, dtype=torch.float64, device="cuda")
+    ctx = _native.host_context(0)
+    cases = (([0, 1, 1, 0], [0, 0], _native.OK, [], ""),
+             ([0, 2, 1, 0], [0, 0], _native.EINVAL, [1], "ray_group"),
+             ([0, -1, 1, 0], [0, 0], _native.EINVAL, [1], "ray_group"),
+             ([0, 1, 1, 0], [0, 5], _native.EINVAL, [1, 2], "profile_index"))
+    for geometry in (0, 1):
+        for groups, gprof, want_rc, bad, word in cases:
+            out = torch.zeros((4, 8), dtype=torch.float64, device="cuda")
+            rg = torch.tensor(groups, dtype=torch.int64, device="cuda")
+            gp = torch.tensor(gprof, dtype=torch.int64, device="cuda")
+            rc = ctx.snell_fan(geometry, gf.data_ptr(), gp.data_ptr(), 2, rg.data_ptr(), e.data_ptr(), 4, prof["den"].data_ptr(),
+                               prof["bmag"].data_ptr(), prof["bpsi"].data_ptr(), alt.data_ptr(), 1, n_alt, 0, _native.MODE_O,
+                               6371.0, 1.0, 200.0, 400, out.data_ptr(), 0, 0, 0, _native.FLAG_DEVICE_PTRS)
+            assert rc == want_rc, (geometry, groups, gprof, rc, _native.last_error())
+            o = out.cpu().numpy()
+            good = [i for i in range(4) if i not in bad]
+            assert np.isfinite(o[good, 0]).all(), (geometry, groups, gprof, o[:, 0])
+            if bad:
+                assert np.isnan(o[bad, 0]).all() and word in _native.last_error(), (geometry, groups, gprof, _native.last_error())
+
+
 def test_recent_kernel_ms_reports_every_launch_of_an_unsynchronised_series():
     """prhf_recent_kernel_ms: five launches enqueued back to back, their device times read afterwards with one
     synchronisation; the newest equals prhf_last_kernel_ms; the context remembers 64."""
