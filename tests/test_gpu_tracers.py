@@ -220,6 +220,32 @@ def test_fan_shares_the_levels_and_changes_nothing(spherical):
 
 
 @pytest.mark.parametrize("spherical", [False, True])
+def test_negative_density_raises_as_in_the_reference(spherical):
+    """den2freq raises on a negative density (reference library.py:93-94, the message pinned by test_core.py), and
+    the tracers call it on the whole column (:1184 / :1566): the per-ray and the grouped launch report it - from the
+    kernels, which look at the columns; a call on columns without one is not disturbed by the call before."""
+    from pyrayhf_amd import synth, tracers
+    alt, den, bmag, bpsi = synth.chapman_profiles(3, 5)
+    bad = den.copy(); bad[1, 400] = -1.0                         # (above every turning point: it is the column that counts)
+    f = np.array([4e6, 6e6, 8e6]); e = np.array([30.0, 50.0, 70.0])
+    ray_fn = tracers.trace_rays_spherical_snells if spherical else tracers.trace_rays_cartesian_snells
+    fan_fn = tracers.trace_fan_spherical_snells if spherical else tracers.trace_fan_cartesian_snells
+    one_fn = tracers.trace_ray_spherical_snells if spherical else tracers.trace_ray_cartesian_snells
+    with pytest.raises(ValueError, match="Density must be non-negative"):
+        ray_fn(f, e, alt, bad, bmag, bpsi, "O", profile_index=np.array([0, 1, 2]))
+    with pytest.raises(ValueError, match="Density must be non-negative"):
+        fan_fn(f, e, alt, bad, bmag, bpsi, "O")
+    with pytest.raises(ValueError, match="Density must be non-negative"):
+        one_fn(6e6, 45.0, alt, bad[1], bmag[1], bpsi[1], "X")
+    good = ray_fn(f, e, alt, den, bmag, bpsi, "O", profile_index=np.array([0, 1, 2]))
+    assert np.isfinite(good["group_path_km"]).any()
+    # rays that do not touch the bad column are not an error
+    ok = ray_fn(f, e, alt, bad, bmag, bpsi, "O", profile_index=np.array([0, 2, 2]))
+    assert np.array_equal(ok["group_path_km"][0], good["group_path_km"][0])
+    assert fan_fn(f, e, alt, den, bmag, bpsi, "O")["group_path_km"].shape == (3, 3, 3)
+
+
+@pytest.mark.parametrize("spherical", [False, True])
 def test_ray_queues_give_every_ray_its_result_whatever_the_count(spherical):
     """The per-ray launch is persistent: wavefronts draw their rays four at a time from eight queues, one per slice of
     the rays (prhf_snell.inc snell_dispatch).  Ray counts that are multiples of nothing, below and above the number of
