@@ -284,7 +284,7 @@ int prhf_snell_spherical_f64(prhf_ctx* ctx, const double* freq_hz, const double*
  * profile 0), ray_group[r] in [0, n_groups), elevation_deg[r].  geometry 0: flat Earth (the four controls are
  * ignored), 1: spherical Earth.  Outputs, paths, flags and errors as for the per-ray calls; the results are those of
  * the per-ray calls on the same rays in PRHF_MATH_FAITHFUL to 1e-15 (other orders of summation).  PRHF_EINVAL when the
- * tables (n_groups x (n_alt + 1) x 52 bytes in the context's scratch) would exceed 64 GiB, and - checked on the host
+ * tables (n_groups x (n_alt + 1) x 44 bytes in the context's scratch) would exceed 64 GiB, and - checked on the host
  * for host buffers, by the kernel for device-resident arrays (reported at the synchronisation) - when a ray_group or
  * a profile index is out of range.
  */

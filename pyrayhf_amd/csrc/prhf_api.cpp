@@ -1365,9 +1365,10 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
     const bool grouped = ray_group != nullptr;
     if (grouped && n_groups < 1) return fail(PRHF_EINVAL, "a grouped launch needs at least one group");
     const int64_t n_keys = grouped ? n_groups : n_rays;          // entries of freq_hz / profile_index
-    // per group and level: mu, mu' (16 B), the compacted entry (32 B), its grid level (4 B); per group: four scalars
+    // per group and level: mu' (8 B), the compacted entry (32 B), its grid level (4 B); per group: four scalars
     const size_t level_cells = grouped ? (size_t)n_groups * (size_t)(n_alt + 1) : 0;
-    const size_t level_bytes = level_cells * 52 + (grouped ? (size_t)n_groups * 16 : 0);
+    const size_t mup_cells = (level_cells + 1) & ~(size_t)1;      // (the entries behind them are read 16 bytes at a time)
+    const size_t level_bytes = mup_cells * 8 + level_cells * 36 + (grouped ? (size_t)n_groups * 16 : 0);
     if (level_bytes > ((size_t)64 << 30) || n_groups > 0x7fffffffLL || (grouped && n_rays > 0x7fffffffLL))
         return fail(PRHF_EINVAL, "level tables of %lld groups exceed 64 GiB (or 2^31 - 1 groups / rays): trace in batches",
                     (long long)n_groups);
@@ -1485,7 +1486,7 @@ int snell_run(prhf_ctx* c, const SnellGeometry& geo, const double* freq_hz, cons
         int rc3 = ensure(c, c->levels, level_bytes);
         if (rc3 != PRHF_OK) return rc3;
         a.levels = static_cast<double*>(c->levels.p);
-        a.group_entries = a.levels + 2 * level_cells;
+        a.group_entries = a.levels + mup_cells;
         a.group_info = reinterpret_cast<int*>(a.group_entries + 4 * level_cells);
         a.group_kidx = a.group_info + 4 * (size_t)n_groups;
     } else {

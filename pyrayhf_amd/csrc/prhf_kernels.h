@@ -257,8 +257,8 @@ struct SnellArgs {
     const double* group_freq;    // (n_groups) [Hz]
     const long long* group_prof; // (n_groups) or null: profile 0
     long long n_groups;
-    double* levels;              // (n_groups, n_alt + 1, 2) mu and mu' of every level (ground level first when inserted)
-    // ... and, made with it once per group (snell_tables_kernel), what every ray of the group would otherwise make itself:
+    double* levels;              // (n_groups, n_alt + 1) mu' of every level (ground level first when inserted)
+    // ... and, made beside it once per group (snell_tables_kernel), what every ray of the group would otherwise make itself:
     double* group_entries;       // (n_groups, n_alt + 1, 4) the levels with a finite mu, compacted: altitude, mu, mu', running
                                  // minimum of the bracket criterion (mu, or mu r on a spherical Earth) over the entries 1 .. i
     int* group_kidx;             // (n_groups, n_alt + 1) grid level of each entry
